@@ -1,0 +1,334 @@
+"""CPU oracle: NumPy restatement of the zopt hot path (TEST INFRASTRUCTURE ONLY).
+
+This file restates, in plain NumPy (fp64 or fp32, following the input dtype), the
+algorithms of the reference ``zprihoda/zopt`` that SURVEY.md section 8(a) puts on the hot
+path.  Every function cites the reference ``file:line`` it follows and keeps the
+reference's operation order (association of the matrix products, Joseph-form update,
+``solve`` = LU with partial pivoting via LAPACK) so that it is as close to the
+reference's own arithmetic as a NumPy program can be.
+
+Batch extension (new in the build): every array may carry extra LEADING axes; with no
+leading axes the functions take and return exactly the reference's shapes.
+
+Pinning status (see DESIGN.md "Oracle"): the reference itself cannot run here (``jax`` /
+``cvxpy`` are not installed: an ordinary ModuleNotFoundError, not a refusal) and it ships
+no fixture files, so this oracle is pinned by the reference's own known-answer tests
+(``tests/test_lqrUtils.py``, ``tests/test_ilqrUtils.py``, ``tests/test_quadcopter.py``,
+``tests/test_pytrees.py`` -- transcribed as data in ``tests/golden/reference_kats.json``)
+and cross-checked against SciPy's DARE solver (``lqrUtils.py:202-203`` is two lines of
+real SciPy).  ``lqrMpc`` (cvxpy -> OSQP 1.0.4) has NO numeric pin in the reference:
+"parity unpinned" -- see ``mpc_*`` below.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg may import
+this module.  The product (``zopt_amd``) never does.
+"""
+from __future__ import annotations
+
+from typing import Callable, NamedTuple
+
+import numpy as np
+
+
+def _T(x):
+    """Matrix transpose of the last two axes (the reference's ``.T`` on 2-D arrays)."""
+    return np.swapaxes(x, -1, -2)
+
+
+def _mv(M, v):
+    """Batched matrix @ vector."""
+    return (M @ v[..., None])[..., 0]
+
+
+# ----------------------------------------------------------------------------------------
+# A1  lqrUtils.discreteFiniteHorizonLqr                      reference lqrUtils.py:144-173
+# ----------------------------------------------------------------------------------------
+def discreteFiniteHorizonLqr(A, B, Q, R, N):
+    """Backward Riccati recursion, Joseph-form value update.
+
+    Follows ``lqrUtils.py:167-172``:
+        V <- Q[-1]                                              (:172, quirk Q1)
+        for k = N-1 .. 0:
+            L_k = solve(R_k + B_k^T V B_k,  B_k^T V A_k)        (:168)
+            V   = Q_k + L_k^T R_k L_k + (A_k-B_k L_k)^T V (A_k-B_k L_k)   (:169)
+    Returns L with shape (..., N, m, n); control law u = -L x (:151).
+    """
+    A, B, Q, R = (np.asarray(x) for x in (A, B, Q, R))
+    V = Q[..., -1, :, :]
+    m = B.shape[-1]
+    n = B.shape[-2]
+    L = np.empty(A.shape[:-3] + (N, m, n), dtype=A.dtype)
+    for k in range(N - 1, -1, -1):
+        Ak, Bk, Qk, Rk = A[..., k, :, :], B[..., k, :, :], Q[..., k, :, :], R[..., k, :, :]
+        BtV = _T(Bk) @ V
+        Lk = np.linalg.solve(Rk + BtV @ Bk, BtV @ Ak)
+        Acl = Ak - Bk @ Lk
+        V = Qk + (_T(Lk) @ Rk) @ Lk + (_T(Acl) @ V) @ Acl
+        L[..., k, :, :] = Lk
+    return L
+
+
+# ----------------------------------------------------------------------------------------
+# A2  lqrUtils.bilinearAffineLqr                             reference lqrUtils.py:207-262
+# ----------------------------------------------------------------------------------------
+def bilinearAffineLqr(A, B, d, Q, R, H, q, r, q0, N):
+    """Finite-horizon LQR with cross term H, affine dynamics d, linear costs q, r, q0.
+
+    Follows ``lqrUtils.py:242-261``; carry (V, v, v0) <- (Q[-1], q[-1], q0[-1]) (:261).
+    Returns (L (..., N, m, n), l (..., N, m)); law u = -L x - l.
+    """
+    A, B, d, Q, R, H, q, r, q0 = (np.asarray(x) for x in (A, B, d, Q, R, H, q, r, q0))
+    n, m = B.shape[-2:]
+    V = Q[..., -1, :, :]
+    v = q[..., -1, :]
+    v0 = q0[..., -1]
+    LArr = np.empty(A.shape[:-3] + (N, m, n), dtype=A.dtype)
+    lArr = np.empty(A.shape[:-3] + (N, m), dtype=A.dtype)
+    for k in range(N - 1, -1, -1):
+        Ak, Bk, dk = A[..., k, :, :], B[..., k, :, :], d[..., k, :]
+        Qk, Rk, Hk = Q[..., k, :, :], R[..., k, :, :], H[..., k, :, :]
+        qk, rk, q0k = q[..., k, :], r[..., k, :], q0[..., k]
+        Vd = _mv(V, dk)
+        Su = rk + _mv(_T(Bk), v) + _mv(_T(Bk), _mv(_T(V), dk))   # r + v^T B + d^T V B      (:244)
+        Suu = Rk + (_T(Bk) @ V) @ Bk                              # (:245)
+        Sux = Hk + (_T(Bk) @ V) @ Ak                              # (:246)
+        L = np.linalg.solve(Suu, Sux)                             # (:248)
+        l = np.linalg.solve(Suu, Su[..., None])[..., 0]           # (:249)
+        VNew = Qk + (_T(Ak) @ V) @ Ak - (_T(L) @ Suu) @ L         # (:251)
+        vNew = qk + _mv(_T(Ak), v + Vd) - _mv(_T(Sux), l)         # (:252)
+        v0New = (v0 + q0k + np.sum(dk * v, -1) + 0.5 * np.sum(dk * Vd, -1)
+                 - 0.5 * np.sum(l * Su, -1))                      # (:253)
+        V, v, v0 = VNew, vNew, v0New
+        LArr[..., k, :, :] = L
+        lArr[..., k, :] = l
+    return LArr, lArr
+
+
+# ----------------------------------------------------------------------------------------
+# A12  layout types                                 reference pytrees.py:6-12,58-69,84-98,
+#                                                   129-136,165-177,207-213
+# ----------------------------------------------------------------------------------------
+class Trajectory(NamedTuple):
+    xTraj: np.ndarray
+    uTraj: np.ndarray
+
+
+class QuadraticValueFunction(NamedTuple):
+    v: np.ndarray
+    v_x: np.ndarray
+    v_xx: np.ndarray
+
+
+class QuadraticCostFunction(NamedTuple):
+    c: np.ndarray
+    c_x: np.ndarray
+    c_u: np.ndarray
+    c_xx: np.ndarray
+    c_ux: np.ndarray
+    c_uu: np.ndarray
+
+
+class AffineDynamics(NamedTuple):
+    f: np.ndarray
+    f_x: np.ndarray
+    f_u: np.ndarray
+
+
+class QuadraticDynamics(NamedTuple):
+    f: np.ndarray
+    f_x: np.ndarray
+    f_u: np.ndarray
+    f_xx: np.ndarray
+    f_ux: np.ndarray
+    f_uu: np.ndarray
+
+
+class AffinePolicy(NamedTuple):
+    l: np.ndarray
+    L: np.ndarray
+
+
+# ----------------------------------------------------------------------------------------
+# A5  ensurePositiveDefinite & friends                    reference ilqrUtils.py:217-257
+# ----------------------------------------------------------------------------------------
+def ensurePositiveDefinite(a, eps=1e-3):
+    """``w, v = eigh(a); (v * max(w, eps)) @ v.T``  (ilqrUtils.py:217-219).
+
+    ``jnp.linalg.eigh`` symmetrises its input by default (symmetrize_input=True):
+    (a + a^H)/2 -- restated explicitly because ``numpy.linalg.eigh`` instead reads only
+    the lower triangle.
+    """
+    a = np.asarray(a)
+    a = 0.5 * (a + _T(a))
+    w, v = np.linalg.eigh(a)
+    return (v * np.maximum(w, eps)[..., None, :]) @ _T(v)
+
+
+def conditionQuadraticCost(cost: QuadraticCostFunction) -> QuadraticCostFunction:
+    """ilqrUtils.py:222-234 -- PD-project the stacked (n+m) cost Hessian per time step."""
+    c, c_x, c_u, c_xx, c_ux, c_uu = cost
+    n = c_xx.shape[-1]
+    m = c_uu.shape[-1]
+    top = np.concatenate([c_xx, _T(c_ux)], axis=-1)
+    bot = np.concatenate([c_ux, c_uu], axis=-1)
+    c_zz = ensurePositiveDefinite(np.concatenate([top, bot], axis=-2))
+    return QuadraticCostFunction(c, c_x, c_u, c_zz[..., :n, :n], c_zz[..., n:, :n], c_zz[..., n:, n:])
+
+
+def conditionValueFunction(Vf: QuadraticValueFunction) -> QuadraticValueFunction:
+    """ilqrUtils.py:254-257."""
+    return QuadraticValueFunction(Vf.v, Vf.v_x, ensurePositiveDefinite(Vf.v_xx))
+
+
+def conditionQuadraticDynamics(dyn: QuadraticDynamics, v_x):
+    """ilqrUtils.py:237-251 -- one time step (leading batch axes allowed)."""
+    _, _, _, f_xx, f_ux, f_uu = dyn
+    vf_xx = np.einsum('...i,...ijk->...jk', v_x, f_xx)
+    vf_uu = np.einsum('...i,...ijk->...jk', v_x, f_uu)
+    vf_ux = np.einsum('...i,...ijk->...jk', v_x, f_ux)
+    n = vf_xx.shape[-1]
+    top = np.concatenate([vf_xx, _T(vf_ux)], axis=-1)
+    bot = np.concatenate([vf_ux, vf_uu], axis=-1)
+    vf_zz = ensurePositiveDefinite(np.concatenate([top, bot], axis=-2))
+    return vf_zz[..., :n, :n], vf_zz[..., n:, :n], vf_zz[..., n:, n:]
+
+
+# ----------------------------------------------------------------------------------------
+# A3  riccatiStep_ilqr / backwardPass_ilqr                reference ilqrUtils.py:153-181
+# ----------------------------------------------------------------------------------------
+def _riccati_tail(Q, Q_x, Q_u, Q_xx, Q_uu, Q_ux):
+    """ilqrUtils.py:167-170 (shared by the iLQR and DDP steps, :200-203)."""
+    l = -np.linalg.solve(Q_uu, Q_u[..., None])[..., 0]
+    L = -np.linalg.solve(Q_uu, Q_ux)
+    Quul = _mv(Q_uu, l)
+    v = Q - 0.5 * np.sum(l * Quul, -1)
+    v_x = Q_x - _mv(_T(L), Quul)
+    v_xx = Q_xx - (_T(L) @ Q_uu) @ L
+    return QuadraticValueFunction(v, v_x, v_xx), AffinePolicy(l, L)
+
+
+def riccatiStep_ilqr(dynamics, cost, value):
+    """One backward step (ilqrUtils.py:153-173); ``dynamics.f`` is unused (:156)."""
+    _, f_x, f_u = dynamics[:3]
+    c, c_x, c_u, c_xx, c_ux, c_uu = (np.asarray(t) for t in cost)
+    v, v_x, v_xx = (np.asarray(t) for t in value)
+    f_x, f_u = np.asarray(f_x), np.asarray(f_u)
+    Q = c + v
+    Q_x = c_x + _mv(_T(f_x), v_x)
+    Q_u = c_u + _mv(_T(f_u), v_x)
+    Q_xx = c_xx + (_T(f_x) @ v_xx) @ f_x
+    Q_uu = c_uu + (_T(f_u) @ v_xx) @ f_u
+    Q_ux = c_ux + (_T(f_u) @ v_xx) @ f_x
+    return _riccati_tail(Q, Q_x, Q_u, Q_xx, Q_uu, Q_ux)
+
+
+def backwardPass_ilqr(dynamics: AffineDynamics, cost: QuadraticCostFunction, Vf: QuadraticValueFunction):
+    """Reverse scan of riccatiStep_ilqr (ilqrUtils.py:176-181).
+
+    Time axis: -3 for matrices, -2 for vectors, -1 for scalars c (leading batch axes allowed).
+    Returns AffinePolicy(l (..., N, m), L (..., N, m, n)).
+    """
+    f, f_x, f_u = (np.asarray(t) for t in dynamics[:3])
+    c, c_x, c_u, c_xx, c_ux, c_uu = (np.asarray(t) for t in cost)
+    N = c.shape[-1]
+    n, m = f_u.shape[-2:]
+    V = QuadraticValueFunction(*(np.asarray(t) for t in Vf))
+    lArr = np.empty(f_u.shape[:-3] + (N, m), dtype=f_x.dtype)
+    LArr = np.empty(f_u.shape[:-3] + (N, m, n), dtype=f_x.dtype)
+    for k in range(N - 1, -1, -1):
+        dyn_k = (None, f_x[..., k, :, :], f_u[..., k, :, :])
+        cost_k = (c[..., k], c_x[..., k, :], c_u[..., k, :], c_xx[..., k, :, :], c_ux[..., k, :, :],
+                  c_uu[..., k, :, :])
+        V, pol = riccatiStep_ilqr(dyn_k, cost_k, V)
+        lArr[..., k, :] = pol.l
+        LArr[..., k, :, :] = pol.L
+    return AffinePolicy(lArr, LArr)
+
+
+# ----------------------------------------------------------------------------------------
+# A4  riccatiStep_ddp / backwardPass_ddp                  reference ilqrUtils.py:184-214
+# ----------------------------------------------------------------------------------------
+def riccatiStep_ddp(dynamics, cost, value):
+    """ilqrUtils.py:184-206."""
+    c, c_x, c_u, c_xx, c_ux, c_uu = (np.asarray(t) for t in cost)
+    v, v_x, v_xx = (np.asarray(t) for t in value)
+    dyn = QuadraticDynamics(*[None if t is None else np.asarray(t) for t in dynamics])
+    f_x, f_u = dyn.f_x, dyn.f_u
+    vf_xx, vf_ux, vf_uu = conditionQuadraticDynamics(dyn, v_x)
+    Q = c + v
+    Q_x = c_x + _mv(_T(f_x), v_x)
+    Q_u = c_u + _mv(_T(f_u), v_x)
+    Q_xx = c_xx + (_T(f_x) @ v_xx) @ f_x + vf_xx
+    Q_uu = c_uu + (_T(f_u) @ v_xx) @ f_u + vf_uu
+    Q_ux = c_ux + (_T(f_u) @ v_xx) @ f_x + vf_ux
+    return _riccati_tail(Q, Q_x, Q_u, Q_xx, Q_uu, Q_ux)
+
+
+def backwardPass_ddp(dynamics: QuadraticDynamics, cost: QuadraticCostFunction, Vf: QuadraticValueFunction):
+    """Reverse scan of riccatiStep_ddp (ilqrUtils.py:209-214)."""
+    f, f_x, f_u, f_xx, f_ux, f_uu = (np.asarray(t) for t in dynamics)
+    c, c_x, c_u, c_xx, c_ux, c_uu = (np.asarray(t) for t in cost)
+    N = c.shape[-1]
+    n, m = f_u.shape[-2:]
+    V = QuadraticValueFunction(*(np.asarray(t) for t in Vf))
+    lArr = np.empty(f_u.shape[:-3] + (N, m), dtype=f_x.dtype)
+    LArr = np.empty(f_u.shape[:-3] + (N, m, n), dtype=f_x.dtype)
+    for k in range(N - 1, -1, -1):
+        dyn_k = (None, f_x[..., k, :, :], f_u[..., k, :, :], f_xx[..., k, :, :, :], f_ux[..., k, :, :, :],
+                 f_uu[..., k, :, :, :])
+        cost_k = (c[..., k], c_x[..., k, :], c_u[..., k, :], c_xx[..., k, :, :], c_ux[..., k, :, :],
+                  c_uu[..., k, :, :])
+        V, pol = riccatiStep_ddp(dyn_k, cost_k, V)
+        lArr[..., k, :] = pol.l
+        LArr[..., k, :, :] = pol.L
+    return AffinePolicy(lArr, LArr)
+
+
+# ----------------------------------------------------------------------------------------
+# A6  trajectoryRollout + AffinePolicy.__call__   reference ilqrUtils.py:33-66, pytrees.py:215-220
+# ----------------------------------------------------------------------------------------
+def trajectoryRollout(x0, dynFun: Callable, policy: AffinePolicy, trajPrev: Trajectory, alpha=1):
+    """for k: u_k = alpha*l_k + L_k (x_k - xPrev_k) + uPrev_k ; x_{k+1} = dynFun(x_k, u_k).
+
+    Single trajectory (the reference's shapes).  ``policy`` may also be a callable
+    ``policy(dx, k=k, alpha=alpha)`` as in the reference's own test (test_ilqrUtils.py:7-22).
+    """
+    xPrev, uPrev = trajPrev
+    N = np.shape(uPrev)[0]
+    x = np.asarray(x0)
+    xs, us = [x], []
+    for k in range(N):
+        dx = x - xPrev[k]
+        if callable(policy):
+            u = policy(dx, k=k, alpha=alpha) + uPrev[k]
+        else:
+            u = alpha * policy.l[k] + policy.L[k] @ dx + uPrev[k]
+        x = dynFun(x, u)
+        xs.append(x)
+        us.append(u)
+    return Trajectory(np.stack(xs), np.stack(us))
+
+
+def trajectoryCost(runningCost: Callable, terminalCost: Callable, traj: Trajectory):
+    """CostFunction.__call__ with k=None (pytrees.py:49-52): sum_k c(x_k,u_k) + c_f(x_N)."""
+    xTraj, uTraj = traj
+    J = 0.0
+    for k in range(uTraj.shape[0]):
+        J = J + runningCost(xTraj[k], uTraj[k])
+    return J + terminalCost(xTraj[-1])
+
+
+# ----------------------------------------------------------------------------------------
+# A7  forwardPass2                                         reference ilqrUtils.py:116-150
+# ----------------------------------------------------------------------------------------
+LINESEARCH_ALPHAS = 0.5 ** np.arange(16)       # ilqrUtils.py:145
+
+
+def forwardPass2(x0, dynFun, runningCost, terminalCost, policy, trajPrev):
+    """16 rollouts at alpha = 0.5**j, take argmin of J (NaN wins, as in NumPy/JAX argmin)."""
+    Js, trajs = [], []
+    for alpha in LINESEARCH_ALPHAS:
+        t = trajectoryRollout(x0, dynFun, policy, trajPrev, alpha=alpha)
+        trajs.append(t)
+        Js.append(trajectoryCost(runningCost, terminalCost, t))
+    idx = int(np.argmin(np.asarray(Js)))
+    return trajs[idx], Js[idx]
