@@ -1,0 +1,59 @@
+/* zopt_amd -- C ABI of the MI355X-native batched LQR / iLQR / MPC solve engine.
+ *
+ * The reference (zprihoda/zopt) is pure Python and has NO FFI layer: its boundary for this path is
+ * the Python signatures of zopt/lqrUtils.py, zopt/ilqrUtils.py and zopt/mpcUtils.py.  This header is
+ * the C-ABI a maintainer would bind underneath those signatures (ctypes stub: INTEGRATION.md).
+ * Each entry point names the reference function (file:line) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - All arrays are C-contiguous with the reference's time-first layout (lqrUtils.py:156-159) and ONE
+ *     extra leading axis `batch` (new in the build; the reference is batch == 1).
+ *   - `*_f64` entry points take DEVICE pointers (hipMalloc / torch ROCm `data_ptr()`), launch
+ *     asynchronously on `stream` (a hipStream_t passed as void*, NULL = default stream) and return
+ *     without synchronising.  `*_host_*` variants take HOST pointers, stage through device memory
+ *     they allocate and free themselves, and synchronise before returning.
+ *   - The caller owns every buffer; the library never retains a pointer after the call returns.
+ *   - Return value: 0 = ok; <0 = ZM_E* below (bad argument / unsupported shape); >0 = hipError_t.
+ *     `zm_last_error()` gives a thread-local message for the last non-zero return.
+ *   - Numerics follow the reference: a singular `solve` propagates inf/NaN, nothing throws.
+ */
+#ifndef ZOPT_AMD_H
+#define ZOPT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZM_OK 0
+#define ZM_EINVAL (-1)       /* null pointer, non-positive size */
+#define ZM_EUNSUPPORTED (-2) /* shape outside what the compiled kernels cover (see zm_lqr_backward_supported) */
+
+/* Library version (major*10000 + minor*100 + patch). */
+int zm_version(void);
+
+/* Thread-local description of the last error returned on this thread ("" if none). */
+const char* zm_last_error(void);
+
+/* 1 if (n, m) is covered by the compiled kernels for the given element size (8 = fp64), else 0. */
+int zm_lqr_backward_supported(int n, int m, int elem_size);
+
+/* Batched discrete finite-horizon LQR backward Riccati recursion (Joseph-form value update).
+ * Replaces: zopt/lqrUtils.py:144-173  discreteFiniteHorizonLqr(A, B, Q, R, N) -> L
+ *     V <- Q[T-1];  for k = T-1..0:  L_k = solve(R_k + B_k^T V B_k, B_k^T V A_k)              (:168)
+ *                                    V = Q_k + L_k^T R_k L_k + (A_k-B_k L_k)^T V (A_k-B_k L_k) (:169)
+ * in : A (batch,T,n,n)  B (batch,T,n,m)  Q (batch,T,n,n)  R (batch,T,m,m)
+ * out: L (batch,T,m,n)          control law u = -L x (lqrUtils.py:151)
+ */
+int zm_lqr_backward_f64(const double* A, const double* B, const double* Q, const double* R, double* L,
+                        int64_t batch, int T, int n, int m, void* stream);
+
+/* Same, HOST pointers (NumPy arrays): allocates device staging, copies in, solves, copies L back. */
+int zm_lqr_backward_host_f64(const double* A, const double* B, const double* Q, const double* R, double* L,
+                             int64_t batch, int T, int n, int m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZOPT_AMD_H */

@@ -1,0 +1,81 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/zopt_amd.h declares, rejects bad arguments without touching a GPU, and the Python surface
+mirrors the reference's names/signatures."""
+import inspect
+import os
+import re
+
+import pytest
+
+from zopt_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "zopt_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(zm_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.lib()
+    names = _declared_symbols()
+    assert names, "no symbols parsed from include/zopt_amd.h"
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/zopt_amd.h but not exported"
+        assert name in _lib.SYMBOLS, f"{name} has no ctypes signature in zopt_amd/_lib.py"
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_version_and_support_matrix():
+    lib = _lib.lib()
+    assert lib.zm_version() >= 100
+    assert lib.zm_lqr_backward_supported(12, 4, 8) == 1
+    assert lib.zm_lqr_backward_supported(4, 1, 8) == 1
+    assert lib.zm_lqr_backward_supported(8, 4, 8) == 1
+    assert lib.zm_lqr_backward_supported(64, 16, 4) == 0   # config 5 (tiled fp32 kernel) not built yet
+    assert lib.zm_lqr_backward_supported(0, 1, 8) == 0
+
+
+def test_bad_arguments_return_codes_without_gpu():
+    lib = _lib.lib()
+    rc = lib.zm_lqr_backward_f64(None, None, None, None, None, 1, 1, 2, 2, None)
+    assert rc == _lib.ZM_EINVAL
+    assert b"null" in lib.zm_last_error()
+    dummy = 0x1000
+    rc = lib.zm_lqr_backward_f64(dummy, dummy, dummy, dummy, dummy, 1, 5, 64, 16, None)
+    assert rc == _lib.ZM_EUNSUPPORTED
+    rc = lib.zm_lqr_backward_f64(dummy, dummy, dummy, dummy, dummy, -1, 5, 2, 2, None)
+    assert rc == _lib.ZM_EINVAL
+    with pytest.raises(ValueError):
+        _lib.check(rc, "x")
+
+
+def test_python_surface_mirrors_reference_signatures():
+    """reference zopt/lqrUtils.py:144 `discreteFiniteHorizonLqr(A, B, Q, R, N)`, :266 proportionalFeedbackController."""
+    from zopt_amd import lqrUtils
+    assert list(inspect.signature(lqrUtils.discreteFiniteHorizonLqr).parameters) == ["A", "B", "Q", "R", "N"]
+    assert list(inspect.signature(lqrUtils.proportionalFeedbackController).parameters) == ["x", "x0", "u0", "K"]
+
+
+def test_product_never_imports_oracle():
+    """The product path must not route through the oracle / any CPU fallback."""
+    pkg = os.path.join(ROOT, "zopt_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f"{f} imports the oracle"
+                assert "zopt_oracle" not in txt and "c_oracle" not in txt, f"{f} references the oracle"
+
+
+def test_no_gpu_means_loud_failure():
+    import numpy as np
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from zopt_amd import lqrUtils
+    I = np.repeat(np.eye(2)[None], 2, axis=0)
+    with pytest.raises(_lib.ZoptAmdError):
+        lqrUtils.discreteFiniteHorizonLqr(I, I, I, I, 2)

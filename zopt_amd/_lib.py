@@ -1,0 +1,78 @@
+"""ctypes binding of the C ABI in ``include/zopt_amd.h`` (``zopt_amd/csrc/libzopt_amd.so``).
+
+The library is loaded lazily; a missing library is a hard error (``ZoptAmdError``) -- the product
+never falls back to a CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libzopt_amd.so")
+
+ZM_OK = 0
+ZM_EINVAL = -1
+ZM_EUNSUPPORTED = -2
+
+# every symbol include/zopt_amd.h declares: name -> (restype, argtypes)
+_c_dp = ctypes.c_void_p
+SYMBOLS = {
+    "zm_version": (ctypes.c_int, []),
+    "zm_last_error": (ctypes.c_char_p, []),
+    "zm_lqr_backward_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "zm_lqr_backward_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, ctypes.c_int64, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "zm_lqr_backward_host_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, ctypes.c_int64, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int]),
+}
+
+
+class ZoptAmdError(RuntimeError):
+    """The HIP library is missing / failed; there is deliberately no fallback."""
+
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 in-tree (``make -C zopt_amd/csrc``)."""
+    out = subprocess.run(["make", "-C", CSRC], capture_output=True, text=True)
+    if verbose or out.returncode != 0:
+        print(out.stdout)
+        print(out.stderr)
+    if out.returncode != 0:
+        raise ZoptAmdError("building libzopt_amd.so failed (hipcc --offload-arch=gfx950)")
+    return LIB_PATH
+
+
+def lib():
+    """The loaded shared library with argtypes set; raises ZoptAmdError if it cannot be loaded."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ZoptAmdError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(zopt_amd has no CPU fallback)")
+        try:
+            handle = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise ZoptAmdError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str):
+    """Map a C-ABI return code to the reference's error conventions (ValueError for bad shapes)."""
+    if rc == ZM_OK:
+        return
+    msg = lib().zm_last_error().decode("utf-8", "replace")
+    if rc in (ZM_EINVAL, ZM_EUNSUPPORTED):
+        raise ValueError(f"{what}: {msg}")
+    raise ZoptAmdError(f"{what}: HIP error {rc}: {msg}")

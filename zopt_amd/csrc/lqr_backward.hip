@@ -1,0 +1,263 @@
+// K1  lqr_backward -- batched discrete finite-horizon LQR backward Riccati recursion, fp64, gfx950.
+//
+// Replaces the arithmetic of zopt/lqrUtils.py:144-173 (discreteFiniteHorizonLqr), per trajectory:
+//     V <- Q[T-1]                                                              (:172)
+//     for k = T-1 .. 0:
+//         L_k = solve(R_k + B_k^T V B_k,  B_k^T V A_k)                         (:168)
+//         V   = Q_k + L_k^T R_k L_k + (A_k - B_k L_k)^T V (A_k - B_k L_k)      (:169)  Joseph form
+//
+// Mapping (see tile16_f64.h): one wave64 per trajectory, stacked index [x(0..n-1) | pad | u at NP..NP+m-1],
+// NP = 4*KS >= n, NP + m <= 16.  Per step, with F = [A_k | B_k] as a 16-column tile:
+//     Y  = V^T F                3 MFMA   (V's D-layout registers read as A operand = V^T; V is symmetric up to
+//                                          rounding, the recursion simply carries V^T on alternate steps)
+//     G  = F^T Y + [0;R]        3 MFMA   rows NP..NP+3 of G = [B^T V A | R + B^T V B]
+//     L  = solve(Suu, Sux)      4x16 tile through LDS, lane-local pivoted LU (tile16_f64.h)
+//     Acl= A - B L              1 MFMA   (negated A operand), C = F
+//     RL = R L                  1 MFMA
+//     W  = V^T Acl              3 MFMA
+//     V' = Q + L^T RL + Acl^T W 4 MFMA
+// A_k, B_k, Q_k, R_k are read ONCE from HBM straight into their MFMA register layouts (every step's
+// matrices are whole 128-B lines: 1152/384/1152/128 B at n=12, m=4), two steps ahead of their use; V never
+// leaves registers; L_k is written once.  Algorithmic HBM traffic: 8*(2n^2 + 2nm + m^2) B per horizon step.
+#include "tile16_f64.h"
+#include "zm_common.h"
+
+namespace zm {
+
+template <int KS>
+struct LqrStepRegs {
+    double F[KS];   // F[4s+g][c]   : A_k (c < n) | B_k (NP <= c < NP+m)      B-operand / A-operand(F^T)
+    double Qd[KS];  // Q_k[4s+g][c] : D-layout accumulator init of V'
+    double Rm;      // R_k[g][c-NP] : D-layout row NP+g accumulator init of G (identity padding for g >= m)
+    double Bt;      // B_k[c][g]    : A-operand of B L
+    double Rt;      // R_k[c][g]    : A-operand of R L
+};
+
+template <int KS>
+struct LqrAddr {
+    const double* pF0;  // row g of the tile; K-step s adds s*dF
+    const double* pQ0;  // row g of Q; K-step s adds s*4*n
+    int dF;             // per-lane K-step stride of pF (4*n for A lanes, 4*m for B lanes)
+    const double* pRm;
+    const double* pBt;
+    const double* pRt;
+    double* pL;
+    int sF;   // per-lane step stride of pF (n*n for A lanes, n*m for B lanes)
+    int nn, nm, mm, q4n;
+    bool rowok[KS];  // 4s+g < n
+    bool vF[KS], vQ[KS], vRm, vBt, vRt, vL;
+    double rm_pad;
+};
+
+// Loads the step the pointers currently address, then moves every pointer one step back in time.
+// Loads are UNCONDITIONAL (lanes outside a matrix read a clamped in-bounds address of the same step and the
+// value is then zeroed): exec-masked loads would put every load in its own branch region and make hipcc
+// fall back to s_waitcnt vmcnt(0), which would serialise the two-steps-ahead prefetch.
+template <int KS>
+__device__ __forceinline__ void lqr_load_step(LqrStepRegs<KS>& d, LqrAddr<KS>& a) {
+    double f[KS], q[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) f[s] = a.pF0[a.rowok[s] ? s * a.dF : 0];
+    a.pF0 -= a.sF;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) q[s] = a.pQ0[a.rowok[s] ? s * a.q4n : 0];
+    a.pQ0 -= a.nn;
+    const double rm = *a.pRm;
+    a.pRm -= a.mm;
+    const double bt = *a.pBt;
+    a.pBt -= a.nm;
+    const double rt = *a.pRt;
+    a.pRt -= a.mm;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        d.F[s] = a.vF[s] ? f[s] : 0.0;
+        d.Qd[s] = a.vQ[s] ? q[s] : 0.0;
+    }
+    d.Rm = a.vRm ? rm : a.rm_pad;
+    d.Bt = a.vBt ? bt : 0.0;
+    d.Rt = a.vRt ? rt : 0.0;
+}
+
+template <int KS, bool PREFETCH>
+__device__ __forceinline__ void lqr_step(double (&V)[KS], LqrStepRegs<KS>& d, LqrAddr<KS>& a, double* smw,
+                                         const int g, const int c) {
+    constexpr int NP = 4 * KS;
+    // Y = V^T F
+    d4 y = zero4();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) y = mfma(V[s], d.F[s], y);
+    // G = F^T Y + [0 ; R]  -> row NP+g : [ B^T V A | R + B^T V B ]
+    d4 gacc = zero4();
+    gacc[KS] = d.Rm;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) gacc = mfma(d.F[s], y[s], gacc);
+    const double mrow = gacc[KS];
+
+    // Accumulator inits consume the step buffer so that it can be refilled two steps ahead.
+    d4 aacc = zero4();
+    d4 vacc = zero4();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        aacc[s] = d.F[s];
+        vacc[s] = d.Qd[s];
+    }
+    const double bt = d.Bt, rt = d.Rt;
+
+    // 4 x 16 tile [Sux | Suu] through LDS: every lane reads all of Suu (broadcast) and its own RHS column.
+    smw[g * 16 + c] = mrow;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double S[4][4], b[4], x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) S[i][j] = smw[i * 16 + NP + j];
+        b[i] = smw[i * 16 + c];
+    }
+    __builtin_amdgcn_wave_barrier();
+    lu_solve4(S, b, x);
+    const double x01 = (g & 1) ? x[1] : x[0];
+    const double x23 = (g & 1) ? x[3] : x[2];
+    double lv = (g & 2) ? x23 : x01;
+    lv = a.vL ? lv : 0.0;  // L_k[g][c], zero outside (g < m, c < n)
+    if (a.vL) *a.pL = lv;
+    a.pL -= a.nm;
+    // Refill this step buffer with step k-2 (issued after the solve: the 4x4 system is the register-pressure peak).
+    if constexpr (PREFETCH) lqr_load_step(d, a);
+
+    // Acl = A - B L   (columns >= NP keep B; they only ever feed padding rows/columns)
+    aacc = mfma<true>(bt, lv, aacc);
+    // RL = R L  (rows 0..m-1 -> D reg 0 == B operand, K-step 0)
+    const d4 racc = mfma(rt, lv, zero4());
+    // W = V^T Acl
+    d4 w = zero4();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) w = mfma(V[s], aacc[s], w);
+    // V' = Q + L^T (R L) + Acl^T W
+    vacc = mfma(lv, racc[0], vacc);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) vacc = mfma(aacc[s], w[s], vacc);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) V[s] = vacc[s];
+}
+
+// KS = NP/4; NC/MC = compile-time n/m (0 = take the runtime arguments); WPB = waves (trajectories) per block.
+template <int KS, int NC, int MC, int WPB>
+__global__ __launch_bounds__(64 * WPB, 4) void lqr_backward_t16_f64(const double* __restrict__ A,
+                                                                 const double* __restrict__ B,
+                                                                 const double* __restrict__ Q,
+                                                                 const double* __restrict__ R,
+                                                                 double* __restrict__ L, const long batch,
+                                                                 const int T, const int n_rt, const int m_rt) {
+    constexpr int NP = 4 * KS;
+    const int n = NC ? NC : n_rt;
+    const int m = MC ? MC : m_rt;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long traj = (long)blockIdx.x * WPB + wave;
+    if (traj >= batch) return;  // whole wave leaves; no block-level barrier is ever used
+    const int g = lane >> 4, c = lane & 15;
+
+    __shared__ double sm[WPB][64];
+    double* smw = sm[wave];
+
+    LqrAddr<KS> a;
+    a.nn = n * n;
+    a.nm = n * m;
+    a.mm = m * m;
+    const bool cA = c < n;
+    const bool cB = (c >= NP) && (c < NP + m);
+    a.sF = cA ? a.nn : a.nm;
+    const long last = (long)(T - 1);
+    const double* At = A + (traj * T + last) * a.nn;
+    const double* Bt = B + (traj * T + last) * a.nm;
+    const double* Qt = Q + (traj * T + last) * a.nn;
+    const double* Rt = R + (traj * T + last) * a.mm;
+    // Rows 4s+g >= n (only when n < NP) read row g's address instead (in bounds) and are zeroed.
+    a.q4n = 4 * n;
+    a.dF = cA ? 4 * n : 4 * m;
+    const bool row0 = g < n;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int row = 4 * s + g;
+        a.rowok[s] = row < n;
+        a.vF[s] = (row < n) && (cA || cB);
+        a.vQ[s] = (row < n) && cA;
+    }
+    a.pF0 = !(row0 && (cA || cB)) ? At : cA ? (At + g * n + c) : (Bt + g * m + (c - NP));
+    a.pQ0 = (row0 && cA) ? (Qt + g * n + c) : Qt;
+    if (!(cA || cB)) a.sF = a.nn;  // clamped lanes walk A
+    a.vRm = (g < m) && cB;
+    a.pRm = a.vRm ? (Rt + g * m + (c - NP)) : Rt;
+    a.rm_pad = (g >= m && c == NP + g) ? 1.0 : 0.0;
+    a.vBt = cA && (g < m);
+    a.pBt = a.vBt ? (Bt + c * m + g) : Bt;
+    a.vRt = (c < m) && (g < m);
+    a.pRt = a.vRt ? (Rt + c * m + g) : Rt;
+    a.vL = (g < m) && cA;
+    a.pL = L + (traj * T + last) * a.nm + g * n + c;
+
+    // d0 <- step T-1, d1 <- step T-2; each step refills its own buffer with the step two back in time.
+    LqrStepRegs<KS> d0, d1;
+    lqr_load_step(d0, a);
+    if (T >= 2) lqr_load_step(d1, a);
+    double V[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) V[s] = d0.Qd[s];  // V <- Q[T-1]   (lqrUtils.py:172)
+
+    int k = T - 1;  // invariant: d0 holds step k, d1 holds step k-1
+    while (k >= 3) {
+        lqr_step<KS, true>(V, d0, a, smw, g, c);
+        lqr_step<KS, true>(V, d1, a, smw, g, c);
+        k -= 2;
+    }
+    // peeled tail (k in {0,1,2}): prefetch only while a step k-2 >= 0 exists
+    if (k == 2) {
+        lqr_step<KS, true>(V, d0, a, smw, g, c);
+        lqr_step<KS, false>(V, d1, a, smw, g, c);
+        lqr_step<KS, false>(V, d0, a, smw, g, c);
+    } else if (k == 1) {
+        lqr_step<KS, false>(V, d0, a, smw, g, c);
+        lqr_step<KS, false>(V, d1, a, smw, g, c);
+    } else {
+        lqr_step<KS, false>(V, d0, a, smw, g, c);
+    }
+}
+
+template <int KS, int NC, int MC>
+static int launch_t16(const double* A, const double* B, const double* Q, const double* R, double* L, int64_t batch,
+                      int T, int n, int m, hipStream_t stream) {
+    constexpr int WPB = 1;
+    const long blocks = (batch + WPB - 1) / WPB;
+    hipLaunchKernelGGL((lqr_backward_t16_f64<KS, NC, MC, WPB>), dim3((unsigned)blocks), dim3(64 * WPB), 0, stream, A,
+                       B, Q, R, L, (long)batch, T, n, m);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+
+}  // namespace zm
+
+extern "C" int zm_lqr_backward_supported(int n, int m, int elem_size) {
+    return (elem_size == 8 && n >= 1 && n <= 12 && m >= 1 && m <= 4) ? 1 : 0;
+}
+
+extern "C" int zm_lqr_backward_f64(const double* A, const double* B, const double* Q, const double* R, double* L,
+                                   int64_t batch, int T, int n, int m, void* stream) {
+    if (!A || !B || !Q || !R || !L) return zm::set_error(ZM_EINVAL, "zm_lqr_backward_f64: null pointer");
+    if (batch < 0 || T < 1 || n < 1 || m < 1)
+        return zm::set_error(ZM_EINVAL, "zm_lqr_backward_f64: bad size batch=%lld T=%d n=%d m=%d", (long long)batch, T,
+                             n, m);
+    if (!zm_lqr_backward_supported(n, m, 8))
+        return zm::set_error(ZM_EUNSUPPORTED, "zm_lqr_backward_f64: (n=%d, m=%d) not covered (need n<=12, m<=4)", n, m);
+    if ((int64_t)T * n * n >= (int64_t)1 << 31 || batch >= ((int64_t)1 << 31))
+        return zm::set_error(ZM_EUNSUPPORTED, "zm_lqr_backward_f64: T*n*n or batch too large");
+    if (batch == 0) return ZM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 12 && m == 4) return zm::launch_t16<3, 12, 4>(A, B, Q, R, L, batch, T, n, m, st);
+    if (n == 8 && m == 4) return zm::launch_t16<2, 8, 4>(A, B, Q, R, L, batch, T, n, m, st);
+    if (n == 4 && m == 1) return zm::launch_t16<1, 4, 1>(A, B, Q, R, L, batch, T, n, m, st);
+    if (n <= 4) return zm::launch_t16<1, 0, 0>(A, B, Q, R, L, batch, T, n, m, st);
+    if (n <= 8) return zm::launch_t16<2, 0, 0>(A, B, Q, R, L, batch, T, n, m, st);
+    return zm::launch_t16<3, 0, 0>(A, B, Q, R, L, batch, T, n, m, st);
+}
