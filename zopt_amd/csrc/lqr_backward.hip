@@ -8,14 +8,15 @@
 //
 // Mapping (see tile16_f64.h): one wave64 per trajectory, stacked index [x(0..n-1) | pad | u at NP..NP+m-1],
 // NP = 4*KS >= n, NP + m <= 16.  Per step, with F = [A_k | B_k] as a 16-column tile:
-//     Y  = V^T F                3 MFMA   (V's D-layout registers read as A operand = V^T; V is symmetric up to
-//                                          rounding, the recursion simply carries V^T on alternate steps)
-//     G  = F^T Y + [0;R]        3 MFMA   rows NP..NP+3 of G = [B^T V A | R + B^T V B]
+//     Y  = V^T F                3 MFMA   (V's D-layout registers read as an A operand are V^T)
+//     G  = Y^T F + [0;R]        3 MFMA   = F^T V F: rows NP..NP+3 of G = [B^T V A | R + B^T V B].  Feeding Y back
+//                                          as the A operand undoes the transpose, so the result is exact for a
+//                                          NONSYMMETRIC V too (nonsymmetric Q/R inputs), as the reference's is.
 //     L  = solve(Suu, Sux)      4x16 tile through LDS, lane-local pivoted LU (tile16_f64.h)
 //     Acl= A - B L              1 MFMA   (negated A operand), C = F
 //     RL = R L                  1 MFMA
 //     W  = V^T Acl              3 MFMA
-//     V' = Q + L^T RL + Acl^T W 4 MFMA
+//     V' = Q + L^T RL + W^T Acl 4 MFMA   (= Q + L^T R L + Acl^T V Acl, the reference's Joseph form)
 // A_k, B_k, Q_k, R_k are read ONCE from HBM straight into their MFMA register layouts (every step's
 // matrices are whole 128-B lines: 1152/384/1152/128 B at n=12, m=4), two steps ahead of their use; V never
 // leaves registers; L_k is written once.  Algorithmic HBM traffic: 8*(2n^2 + 2nm + m^2) B per horizon step.
@@ -86,11 +87,11 @@ __device__ __forceinline__ void lqr_step(double (&V)[KS], LqrStepRegs<KS>& d, Lq
     d4 y = zero4();
 #pragma unroll
     for (int s = 0; s < KS; ++s) y = mfma(V[s], d.F[s], y);
-    // G = F^T Y + [0 ; R]  -> row NP+g : [ B^T V A | R + B^T V B ]
+    // G = Y^T F + [0 ; R] = F^T V F + [0 ; R]  -> row NP+g : [ B^T V A | R + B^T V B ]
     d4 gacc = zero4();
     gacc[KS] = d.Rm;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) gacc = mfma(d.F[s], y[s], gacc);
+    for (int s = 0; s < KS; ++s) gacc = mfma(y[s], d.F[s], gacc);
     const double mrow = gacc[KS];
 
     // Accumulator inits consume the step buffer so that it can be refilled two steps ahead.
@@ -134,10 +135,10 @@ __device__ __forceinline__ void lqr_step(double (&V)[KS], LqrStepRegs<KS>& d, Lq
     d4 w = zero4();
 #pragma unroll
     for (int s = 0; s < KS; ++s) w = mfma(V[s], aacc[s], w);
-    // V' = Q + L^T (R L) + Acl^T W
+    // V' = Q + L^T (R L) + W^T Acl = Q + L^T R L + Acl^T V Acl
     vacc = mfma(lv, racc[0], vacc);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) vacc = mfma(aacc[s], w[s], vacc);
+    for (int s = 0; s < KS; ++s) vacc = mfma(w[s], aacc[s], vacc);
 #pragma unroll
     for (int s = 0; s < KS; ++s) V[s] = vacc[s];
 }
@@ -168,16 +169,20 @@ __global__ __launch_bounds__(64 * WPB, 4) void lqr_backward_t16_f64(const double
     a.mm = m * m;
     const bool cA = c < n;
     const bool cB = (c >= NP) && (c < NP + m);
-    a.sF = cA ? a.nn : a.nm;
     const long last = (long)(T - 1);
     const double* At = A + (traj * T + last) * a.nn;
     const double* Bt = B + (traj * T + last) * a.nm;
     const double* Qt = Q + (traj * T + last) * a.nn;
     const double* Rt = R + (traj * T + last) * a.mm;
-    // Rows 4s+g >= n (only when n < NP) read row g's address instead (in bounds) and are zeroed.
-    a.q4n = 4 * n;
-    a.dF = cA ? 4 * n : 4 * m;
+    // Lanes / rows outside the matrices read an in-bounds address of the same step (element 0 of A_k, or
+    // row g when only the K-step row 4s+g is out of range) and are zeroed after the load.  Base pointer,
+    // K-step stride and step stride are always chosen TOGETHER so a clamped lane never leaves its array.
     const bool row0 = g < n;
+    const bool laneA = row0 && cA;   // reads A_k[4s+g][c]
+    const bool laneB = row0 && cB;   // reads B_k[4s+g][c-NP]
+    a.q4n = 4 * n;
+    a.dF = laneA ? 4 * n : laneB ? 4 * m : 0;
+    a.sF = laneB ? a.nm : a.nn;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const int row = 4 * s + g;
@@ -185,9 +190,9 @@ __global__ __launch_bounds__(64 * WPB, 4) void lqr_backward_t16_f64(const double
         a.vF[s] = (row < n) && (cA || cB);
         a.vQ[s] = (row < n) && cA;
     }
-    a.pF0 = !(row0 && (cA || cB)) ? At : cA ? (At + g * n + c) : (Bt + g * m + (c - NP));
-    a.pQ0 = (row0 && cA) ? (Qt + g * n + c) : Qt;
-    if (!(cA || cB)) a.sF = a.nn;  // clamped lanes walk A
+    a.pF0 = laneA ? (At + g * n + c) : laneB ? (Bt + g * m + (c - NP)) : At;
+    a.pQ0 = laneA ? (Qt + g * n + c) : Qt;
+    if (!laneA) a.q4n = 0;
     a.vRm = (g < m) && cB;
     a.pRm = a.vRm ? (Rt + g * m + (c - NP)) : Rt;
     a.rm_pad = (g >= m && c == NP + g) ? 1.0 : 0.0;
