@@ -20,19 +20,12 @@
 // A_k, B_k, Q_k, R_k are read ONCE from HBM straight into their MFMA register layouts (every step's
 // matrices are whole 128-B lines: 1152/384/1152/128 B at n=12, m=4), two steps ahead of their use; V never
 // leaves registers; L_k is written once.  Algorithmic HBM traffic: 8*(2n^2 + 2nm + m^2) B per horizon step.
-#include "tile16_f64.h"
+#include "lqr_step_core.h"
 #include "zm_common.h"
 
-namespace zm {
+#include <cstdlib>
 
-template <int KS>
-struct LqrStepRegs {
-    double F[KS];   // F[4s+g][c]   : A_k (c < n) | B_k (NP <= c < NP+m)      B-operand / A-operand(F^T)
-    double Qd[KS];  // Q_k[4s+g][c] : D-layout accumulator init of V'
-    double Rm;      // R_k[g][c-NP] : D-layout row NP+g accumulator init of G (identity padding for g >= m)
-    double Bt;      // B_k[c][g]    : A-operand of B L
-    double Rt;      // R_k[c][g]    : A-operand of R L
-};
+namespace zm {
 
 template <int KS>
 struct LqrAddr {
@@ -82,65 +75,12 @@ __device__ __forceinline__ void lqr_load_step(LqrStepRegs<KS>& d, LqrAddr<KS>& a
 template <int KS, bool PREFETCH>
 __device__ __forceinline__ void lqr_step(double (&V)[KS], LqrStepRegs<KS>& d, LqrAddr<KS>& a, double* smw,
                                          const int g, const int c) {
-    constexpr int NP = 4 * KS;
-    // Y = V^T F
-    d4 y = zero4();
-#pragma unroll
-    for (int s = 0; s < KS; ++s) y = mfma(V[s], d.F[s], y);
-    // G = Y^T F + [0 ; R] = F^T V F + [0 ; R]  -> row NP+g : [ B^T V A | R + B^T V B ]
-    d4 gacc = zero4();
-    gacc[KS] = d.Rm;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) gacc = mfma(y[s], d.F[s], gacc);
-    const double mrow = gacc[KS];
-
-    // Accumulator inits consume the step buffer so that it can be refilled two steps ahead.
-    d4 aacc = zero4();
-    d4 vacc = zero4();
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        aacc[s] = d.F[s];
-        vacc[s] = d.Qd[s];
-    }
-    const double bt = d.Bt, rt = d.Rt;
-
-    // 4 x 16 tile [Sux | Suu] through LDS: every lane reads all of Suu (broadcast) and its own RHS column.
-    smw[g * 16 + c] = mrow;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double S[4][4], b[4], x[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) S[i][j] = smw[i * 16 + NP + j];
-        b[i] = smw[i * 16 + c];
-    }
-    __builtin_amdgcn_wave_barrier();
-    lu_solve4(S, b, x);
-    const double x01 = (g & 1) ? x[1] : x[0];
-    const double x23 = (g & 1) ? x[3] : x[2];
-    double lv = (g & 2) ? x23 : x01;
-    lv = a.vL ? lv : 0.0;  // L_k[g][c], zero outside (g < m, c < n)
+    // Refill this step buffer with step k-2 only after the solve: the 4x4 system is the register-pressure peak.
+    const double lv = lqr_step_core<KS>(V, d, smw, g, c, a.vL, [&]() {
+        if constexpr (PREFETCH) lqr_load_step(d, a);
+    });
     if (a.vL) *a.pL = lv;
     a.pL -= a.nm;
-    // Refill this step buffer with step k-2 (issued after the solve: the 4x4 system is the register-pressure peak).
-    if constexpr (PREFETCH) lqr_load_step(d, a);
-
-    // Acl = A - B L   (columns >= NP keep B; they only ever feed padding rows/columns)
-    aacc = mfma<true>(bt, lv, aacc);
-    // RL = R L  (rows 0..m-1 -> D reg 0 == B operand, K-step 0)
-    const d4 racc = mfma(rt, lv, zero4());
-    // W = V^T Acl
-    d4 w = zero4();
-#pragma unroll
-    for (int s = 0; s < KS; ++s) w = mfma(V[s], aacc[s], w);
-    // V' = Q + L^T (R L) + W^T Acl = Q + L^T R L + Acl^T V Acl
-    vacc = mfma(lv, racc[0], vacc);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) vacc = mfma(w[s], aacc[s], vacc);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) V[s] = vacc[s];
 }
 
 // KS = NP/4; NC/MC = compile-time n/m (0 = take the runtime arguments); WPB = waves (trajectories) per block.
@@ -241,6 +181,10 @@ static int launch_t16(const double* A, const double* B, const double* Q, const d
     return ZM_OK;
 }
 
+// lqr_backward_dma.hip: LDS-DMA staged fast path (even n, m; 16-B aligned pointers); ZM_EUNSUPPORTED otherwise.
+int lqr_backward_dma_dispatch(const double* A, const double* B, const double* Q, const double* R, double* L,
+                              int64_t batch, int T, int n, int m, hipStream_t stream);
+
 }  // namespace zm
 
 extern "C" int zm_lqr_backward_supported(int n, int m, int elem_size) {
@@ -259,6 +203,15 @@ extern "C" int zm_lqr_backward_f64(const double* A, const double* B, const doubl
         return zm::set_error(ZM_EUNSUPPORTED, "zm_lqr_backward_f64: T*n*n or batch too large");
     if (batch == 0) return ZM_OK;
     hipStream_t st = (hipStream_t)stream;
+    // ZOPT_AMD_LQR_PATH=reg forces the register-prefetch kernel (A/B measurements); default: LDS-DMA when eligible.
+    static const bool force_reg = [] {
+        const char* e = getenv("ZOPT_AMD_LQR_PATH");
+        return e && e[0] == 'r';
+    }();
+    if (!force_reg) {
+        const int rc = zm::lqr_backward_dma_dispatch(A, B, Q, R, L, batch, T, n, m, st);
+        if (rc != ZM_EUNSUPPORTED) return rc;
+    }
     if (n == 12 && m == 4) return zm::launch_t16<3, 12, 4>(A, B, Q, R, L, batch, T, n, m, st);
     if (n == 8 && m == 4) return zm::launch_t16<2, 8, 4>(A, B, Q, R, L, batch, T, n, m, st);
     if (n == 4 && m == 1) return zm::launch_t16<1, 4, 1>(A, B, Q, R, L, batch, T, n, m, st);

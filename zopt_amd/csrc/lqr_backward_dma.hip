@@ -1,0 +1,265 @@
+// K1 (fast path)  lqr_backward, fp64, LDS-DMA staged, 12 MFMA / step -- gfx950.
+//
+// Arithmetic: the reference's Joseph-form recursion (zopt/lqrUtils.py:167-172), per trajectory
+//     V <- Q[T-1];  for k = T-1..0:  L_k = solve(R_k + B_k^T V B_k, B_k^T V A_k)
+//                                    V   = Q_k + L_k^T R_k L_k + (A_k - B_k L_k)^T V (A_k - B_k L_k)
+// on the tile-16 mapping of tile16_f64.h (one wave64 per trajectory, stacked index [x | u], n + m = 16 or 12).
+//
+// What the hardware measurements dictated (profiles/README.md): on gfx950 the fp64 MFMA (64 cycles) and the
+// fp64/32-bit VALU share one issue pipe (SQ_VALU_MFMA_COEXEC_CYCLES = 0), so a step costs
+// 64 * #MFMA + 4 * #VALU cycles per wave and four waves per SIMD add up.  Hence:
+//
+//   operands   HBM --global_load_lds_dwordx4 (16 B/lane, coalesced, memory order)--> LDS ring slot --ds_read_b64-->
+//              MFMA register layouts.  In-flight data costs no VGPRs, the ring runs D = 3 steps ahead, B^T / R
+//              layouts are just other LDS reads of the same bytes; lanes that must read 0 read the slot's padding,
+//              which idle DMA lanes fill from a zero source (no per-step masking instructions).
+//   Y  = V^T F                    3 MFMA     F = [A_k | B_k]
+//   G  = Y^T F + [0 ; R]          3 MFMA     rows n.. of G = [B^T V A | R + B^T V B]
+//   L  = solve(Suu, Sux)          4 x 16 tile through LDS; lane-local elimination WITHOUT row exchanges when every
+//                                 multiplier is <= 4 in magnitude (checked, wave-uniform), else the pivoted LU
+//   [Acl ; -R L] = [A ; 0] + [B ; R] (-L)     1 MFMA   (stacked A operand: rows < n give A - B L, rows n.. give -R L)
+//   W  = V^T Acl = Y_A + Y_B (-L) 1 MFMA     (Y_B = V^T B is already in Y; transposed through LDS off the critical path)
+//   V' = Q + (-L)^T (-R L) + W^T Acl         4 MFMA
+//
+// Requirements: n in {8, 12}, m = 4 (every per-step matrix a multiple of 16 B, all K-step rows live) and 16-B aligned
+// base pointers; every other supported shape runs the register-prefetch kernel in lqr_backward.hip.
+#include "tile16_f64.h"
+#include "zm_common.h"
+
+namespace zm {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+// 16 B of zeros: DMA source of the idle lanes, so that every ring slot's padding reads 0.0.
+__device__ __attribute__((aligned(16))) const double zm_zero_src[2] = {0.0, 0.0};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_imm() {
+    static_assert(N >= 0 && N <= 12, "vmcnt immediate");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+
+// DMA groups retire in issue order and are issued in decreasing step order, so when step j is consumed exactly
+// min(D-1, j) younger groups may still be in flight.  (The L_k stores are NOT counted: that only over-waits.)
+template <int NI, int D>
+__device__ __forceinline__ void wait_for_step(const int j) {
+    if (j >= D - 1) {
+        wait_vmcnt_imm<NI*(D - 1)>();
+    } else if (D >= 3 && j == 1) {
+        wait_vmcnt_imm<NI>();
+    } else if (D >= 4 && j == 2) {
+        wait_vmcnt_imm<2 * NI>();
+    } else {
+        wait_vmcnt_imm<0>();
+    }
+}
+
+template <int N, int M>
+struct DmaGeom {
+    static constexpr int KS = N / 4;
+    static constexpr int NP = N;
+    static constexpr int CA = N * N / 2, CB = N * M / 2, CR = M * M / 2;  // 16-B chunks per step
+    static constexpr int CT = 2 * CA + CB + CR;
+    static constexpr int NI = (CT + 63) / 64;   // DMA wave-instructions per step
+    static constexpr int SLOT = NI * 1024;      // bytes per ring slot
+    static constexpr int OA = 0, OB = CA * 16, OQ = (CA + CB) * 16, OR = (2 * CA + CB) * 16;  // byte offsets in a slot
+    static constexpr int OZ = CT * 16;          // first byte of the zero padding
+    static_assert(N % 4 == 0 && N >= 4 && N <= 12 && M == 4, "fast path: all K-step rows live, m = 4");
+    static_assert(SLOT - OZ >= 16, "slot needs zero padding");
+};
+
+template <int N, int M, int D>
+struct DmaState {
+    using G = DmaGeom<N, M>;
+    const char* p[G::NI];  // per-lane source address of the next step to fetch, one per DMA instruction
+    int st[G::NI];         // per-lane byte stride between consecutive steps of that array (0 for the zero source)
+    int oF, dF;            // LDS byte offset of F[g][c] in a slot and its K-step stride (A lanes 4n*8, B lanes 4m*8)
+    int oQ, oRm, oBR;      // LDS byte offsets (in a slot) of Q[g][c], R[g][c-n] (or zero pad), [B ; R][c][g]
+};
+
+template <int N, int M, int D>
+__device__ __forceinline__ void dma_issue(DmaState<N, M, D>& a, char* slot) {
+    using G = DmaGeom<N, M>;
+#pragma unroll
+    for (int i = 0; i < G::NI; ++i) {
+        __builtin_amdgcn_global_load_lds((glb_void_t*)a.p[i], (lds_void_t*)(slot + i * 1024), 16, 0, 0);
+        a.p[i] -= a.st[i];
+    }
+}
+
+template <int N, int M, int D>
+__global__ __launch_bounds__(64, 4) void lqr_backward_dma_f64(const double* __restrict__ A,
+                                                              const double* __restrict__ B,
+                                                              const double* __restrict__ Q,
+                                                              const double* __restrict__ R, double* __restrict__ L,
+                                                              const int T) {
+    using G = DmaGeom<N, M>;
+    constexpr int KS = G::KS, NI = G::NI, SLOT = G::SLOT;
+    constexpr int nn = N * N, nm = N * M, mm = M * M;
+    // ONE LDS object: D ring slots | 4x16 exchange tile of the solve | Y_B = V^T B (n x 4) for the W product.
+    constexpr int EXCH = D * SLOT, YBO = EXCH + 64 * 8;
+    __shared__ __attribute__((aligned(16))) char lds[YBO + N * M * 8];
+    double* exch = (double*)(lds + EXCH);
+
+    const int lane = threadIdx.x;
+    const long traj = blockIdx.x;
+    const int g = lane >> 4, c = lane & 15;
+    const bool cA = c < N;                    // state column
+    const bool cB = (c >= N) && (c < N + M);  // control column
+
+    DmaState<N, M, D> a;
+    {
+        const long last = traj * T + (T - 1);
+        const char* At = (const char*)(A + last * nn);
+        const char* Bt = (const char*)(B + last * nm);
+        const char* Qt = (const char*)(Q + last * nn);
+        const char* Rt = (const char*)(R + last * mm);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int q = i * 64 + lane;  // 16-B chunk index inside the step's [A|B|Q|R|0-pad] image
+            if (q < G::CA) {
+                a.p[i] = At + q * 16;
+                a.st[i] = nn * 8;
+            } else if (q < G::CA + G::CB) {
+                a.p[i] = Bt + (q - G::CA) * 16;
+                a.st[i] = nm * 8;
+            } else if (q < 2 * G::CA + G::CB) {
+                a.p[i] = Qt + (q - G::CA - G::CB) * 16;
+                a.st[i] = nn * 8;
+            } else if (q < G::CT) {
+                a.p[i] = Rt + (q - 2 * G::CA - G::CB) * 16;
+                a.st[i] = mm * 8;
+            } else {  // idle lanes: zero-fill the slot's padding
+                a.p[i] = (const char*)zm_zero_src;
+                a.st[i] = 0;
+            }
+        }
+    }
+    // MFMA operand addresses inside a slot.  Lanes outside a matrix either read finite don't-care data (they only
+    // ever feed padding rows/columns of the tile) or, where a true zero is required (R's accumulator init under
+    // the state columns), the zero padding.
+    a.oF = cA ? (G::OA + (g * N + c) * 8) : cB ? (G::OB + (g * M + (c - N)) * 8) : G::OZ;
+    a.dF = cA ? 4 * N * 8 : cB ? 4 * M * 8 : 0;
+    a.oQ = G::OQ + (g * N + (cA ? c : 0)) * 8;
+    a.oRm = cB ? (G::OR + (g * M + (c - N)) * 8) : G::OZ;
+    a.oBR = cA ? (G::OB + (c * M + g) * 8) : cB ? (G::OR + ((c - N) * M + g) * 8) : G::OZ;
+    const int oYBw = YBO + (g * M + (c - N)) * 8;           // Y_B[4r+g][c-n]   (+ r*4*M*8), lanes cB
+    const int oYBr = YBO + ((cA ? c : 0) * M + g) * 8;      // Y_B[c][g]        A operand of Y_B (-L)
+    const bool vL = cA;                                     // (g < M always: M == 4)
+    double* pL = L + (traj * T + (T - 1)) * nm + g * N + c;
+
+    // prologue: fill the ring with steps T-1 .. T-D
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+        if (T - 1 - i >= 0) dma_issue<N, M, D>(a, lds + i * SLOT);
+
+    double V[KS];
+    int j = T - 1;  // step index; step j lives in slot (T-1-j) % D
+    bool first = true;
+    for (;;) {
+#pragma unroll
+        for (int si = 0; si < D; ++si) {
+            char* slot = lds + si * SLOT;
+            wait_for_step<NI, D>(j);
+            d4 f4 = zero4(), q4 = zero4();
+#pragma unroll
+            for (int s = 0; s < KS; ++s) f4[s] = *(const double*)(slot + a.oF + s * a.dF);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) q4[s] = *(const double*)(slot + a.oQ + s * (4 * N * 8));
+            const double rm = *(const double*)(slot + a.oRm);
+            const double br = *(const double*)(slot + a.oBR);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // operands are in registers: the slot may be refilled
+            if (j - D >= 0) dma_issue<N, M, D>(a, slot);
+            if (first) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) V[s] = q4[s];  // V <- Q[T-1]   (lqrUtils.py:172)
+                first = false;
+            }
+
+            // Y = V^T F
+            d4 y = zero4();
+#pragma unroll
+            for (int s = 0; s < KS; ++s) y = mfma(V[s], f4[s], y);
+            // Y_B = Y[:, n..n+3] -> LDS (transposed read later); off the critical path
+            if (cB) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) *(double*)(lds + oYBw + s * (4 * M * 8)) = y[s];
+            }
+            // G = Y^T F + [0 ; R]  -> row n+g : [ B^T V A | R + B^T V B ]
+            d4 gacc = zero4();
+#pragma unroll
+            for (int s = 0; s < KS; ++s) gacc = mfma(y[s], f4[s], gacc);
+
+            // m x m solve: 4 x 16 tile through LDS, every lane reads Suu (broadcast) and its own RHS column
+            exch[g * 16 + c] = gacc[KS] + rm;  // (+ R under the control columns, + 0.0 from the padding elsewhere)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double S[4][4], b[4], x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) S[i][jj] = exch[i * 16 + N + jj];
+                b[i] = exch[i * 16 + c];
+            }
+            const double ybt = *(const double*)(lds + oYBr);
+            if (!__all(lu_solve4_nopivot(S, b, x))) {
+                // rare: growth check failed somewhere in the wave -> partial pivoting, IEEE division
+                lu_solve4(S, b, x);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const double x01 = (g & 1) ? x[1] : x[0];
+            const double x23 = (g & 1) ? x[3] : x[2];
+            const double lv = (g & 2) ? x23 : x01;  // L_k[g][c]
+            const double ln = -lv;
+            if (vL) *pL = lv;
+            pL -= nm;
+
+            // [Acl ; -R L] = [A ; 0] + [B ; R] (-L)
+            f4 = mfma(br, ln, f4);
+            // W = Y + Y_B (-L)  = V^T (A - B L)
+            y = mfma(ybt, ln, y);
+            // V' = Q + (-L)^T (-R L) + W^T Acl
+            q4 = mfma(ln, f4[KS], q4);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) q4 = mfma(y[s], f4[s], q4);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) V[s] = q4[s];
+            if (--j < 0) return;
+        }
+    }
+}
+
+template <int N, int M>
+static int launch_dma(const double* A, const double* B, const double* Q, const double* R, double* L, int64_t batch,
+                      int T, hipStream_t stream) {
+    constexpr int D = 3;
+    hipLaunchKernelGGL((lqr_backward_dma_f64<N, M, D>), dim3((unsigned)batch), dim3(64), 0, stream, A, B, Q, R, L, T);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+
+// Returns ZM_EUNSUPPORTED when the shape / alignment is not covered so that the caller falls back.
+int lqr_backward_dma_dispatch(const double* A, const double* B, const double* Q, const double* R, double* L,
+                              int64_t batch, int T, int n, int m, hipStream_t stream) {
+    const uintptr_t al = (uintptr_t)A | (uintptr_t)B | (uintptr_t)Q | (uintptr_t)R;
+    if (al & 15) return ZM_EUNSUPPORTED;
+    if (n == 12 && m == 4) return launch_dma<12, 4>(A, B, Q, R, L, batch, T, stream);
+    if (n == 8 && m == 4) return launch_dma<8, 4>(A, B, Q, R, L, batch, T, stream);
+    return ZM_EUNSUPPORTED;
+}
+
+}  // namespace zm

@@ -71,4 +71,52 @@ __device__ __forceinline__ void lu_solve4(double (&S)[4][4], double (&b)[4], dou
     }
 }
 
+// 1/a to fp64 accuracy (<= ~1 ulp) from v_rcp_f64 and two Newton steps; ~half the issue cost of the IEEE
+// division sequence.  a = 0, inf, NaN or denormal-range pivots give inf/NaN here -- callers test the result and
+// take the IEEE / pivoted path in that case.
+__device__ __forceinline__ double fast_rcp(const double a) {
+    double r = __builtin_amdgcn_rcp(a);
+    double e = __builtin_fma(-a, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-a, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+
+// Fast path of the m x m solve: Gaussian elimination WITHOUT row exchanges (no register shuffling at all),
+// valid whenever partial pivoting is not needed for stability.  Returns false -- and the caller must redo the
+// solve with lu_solve4 (pivoted, IEEE division) -- unless every multiplier satisfies |l_ik| <= 4 (element growth
+// then stays <= 5^3) and every pivot reciprocal is finite.  NaN compares false, so NaN/zero pivots always take
+// the pivoted path and inf/NaN propagate exactly as there.  Differs from the pivoted path only by rounding.
+__device__ __forceinline__ bool lu_solve4_nopivot(const double (&S)[4][4], const double (&b)[4], double (&x)[4]) {
+    const double lim = 4.0;
+    const double r0 = fast_rcp(S[0][0]);
+    const double f10 = S[1][0] * r0, f20 = S[2][0] * r0, f30 = S[3][0] * r0;
+    bool ok = (__builtin_fabs(f10) <= lim) & (__builtin_fabs(f20) <= lim) & (__builtin_fabs(f30) <= lim);
+    const double a11 = __builtin_fma(-f10, S[0][1], S[1][1]), a12 = __builtin_fma(-f10, S[0][2], S[1][2]);
+    const double a13 = __builtin_fma(-f10, S[0][3], S[1][3]), b1 = __builtin_fma(-f10, b[0], b[1]);
+    const double a21 = __builtin_fma(-f20, S[0][1], S[2][1]), a22 = __builtin_fma(-f20, S[0][2], S[2][2]);
+    const double a23 = __builtin_fma(-f20, S[0][3], S[2][3]), b2 = __builtin_fma(-f20, b[0], b[2]);
+    const double a31 = __builtin_fma(-f30, S[0][1], S[3][1]), a32 = __builtin_fma(-f30, S[0][2], S[3][2]);
+    const double a33 = __builtin_fma(-f30, S[0][3], S[3][3]), b3 = __builtin_fma(-f30, b[0], b[3]);
+    const double r1 = fast_rcp(a11);
+    const double f21 = a21 * r1, f31 = a31 * r1;
+    ok &= (__builtin_fabs(f21) <= lim) & (__builtin_fabs(f31) <= lim);
+    const double c22 = __builtin_fma(-f21, a12, a22), c23 = __builtin_fma(-f21, a13, a23);
+    const double d2 = __builtin_fma(-f21, b1, b2);
+    const double c32 = __builtin_fma(-f31, a12, a32), c33 = __builtin_fma(-f31, a13, a33);
+    const double d3 = __builtin_fma(-f31, b1, b3);
+    const double r2 = fast_rcp(c22);
+    const double f32 = c32 * r2;
+    ok &= (__builtin_fabs(f32) <= lim);
+    const double e33 = __builtin_fma(-f32, c23, c33), g3 = __builtin_fma(-f32, d2, d3);
+    const double r3 = fast_rcp(e33);
+    ok &= (__builtin_fabs(r3) <= 1.79769313486231570815e308);
+    x[3] = g3 * r3;
+    x[2] = __builtin_fma(-c23, x[3], d2) * r2;
+    x[1] = __builtin_fma(-a13, x[3], __builtin_fma(-a12, x[2], b1)) * r1;
+    x[0] = __builtin_fma(-S[0][3], x[3], __builtin_fma(-S[0][2], x[2], __builtin_fma(-S[0][1], x[1], b[0]))) * r0;
+    return ok;
+}
+
 }  // namespace zm
