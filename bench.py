@@ -41,21 +41,44 @@ def make_inputs(batch, T, n, m, seed, device):
     return out
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota (GPU boxes give a
+    one-GPU job a share of the host, e.g. 16 of 256 hardware threads)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(batch, T, n, m, target_seconds=10.0):
     """Times the plain-C oracle (a port of lqrUtils.py:167-172) on all host cores over the same workload."""
     from oracle import c_oracle
     from tests import problems
     A1, B1, Q1, R1 = problems.random_lti_systems(batch, n, m, seed=0)
     A, B, Q, R = problems.tile_over_horizon(A1, B1, Q1, R1, T)
-    cores = c_oracle.num_threads()
-    c_oracle.lqr_backward(A[:64], B[:64], Q[:64], R[:64])  # warm-up
+    cores = min(c_oracle.num_threads(), usable_cores())
+    c_oracle.lqr_backward(A[:64], B[:64], Q[:64], R[:64], nthreads=cores)  # warm-up
+    c_oracle.lqr_backward(A, B, Q, R, nthreads=cores)      # warm-up of the full-size call (thread pool, page faults)
     reps, elapsed = 0, 0.0
     t0 = time.perf_counter()
     while True:
-        c_oracle.lqr_backward(A, B, Q, R)
+        c_oracle.lqr_backward(A, B, Q, R, nthreads=cores)
         reps += 1
         elapsed = time.perf_counter() - t0
-        if elapsed * cores >= target_seconds or reps >= 50:   # ~target_seconds of CPU work summed over cores
+        # bounded sample: ~target_seconds of CPU work summed over cores, but at least 1 s of wall time
+        if (elapsed * cores >= target_seconds and elapsed >= 1.0) or elapsed >= 20.0:
             break
     return {"value": batch * T * reps / elapsed, "unit": "horizon-steps/s", "cores": cores, "kind": "port",
             "sample": f"full workload ({batch} trajectories x T={T}, n={n}, m={m}, fp64) x {reps} reps, "
@@ -162,7 +185,7 @@ def main():
                        "batch_per_gpu": batch, "T": T, "n": n, "m": m, "parallelism": f"batch-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "lqr_backward_t16_f64", "kernel_ms": kern_ms,
+                         "kernel": "lqr_backward_dma_f64<12,4,3>" if (n, m) == (12, 4) else "lqr_backward", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": bps * steps_per_launch},
         }
         if gather_ms is not None:

@@ -27,23 +27,25 @@
 #define ZO_MAXN 64
 #define ZO_MAXM 16
 
-/* C[p x r] = A^T[p x q] * B[q x r], A stored q x p */
+/* C[p x r] = A^T[p x q] * B[q x r], A stored q x p.  Loop order k-i-j keeps the inner loop contiguous so gcc
+ * vectorises it; each C[i][j] is still the k-ordered sum the reference's matmul forms. */
 static void atb(const double *A, const double *B, double *C, int q, int p, int r) {
-    for (int i = 0; i < p; ++i)
-        for (int j = 0; j < r; ++j) {
-            double s = 0.0;
-            for (int k = 0; k < q; ++k) s += A[k * p + i] * B[k * r + j];
-            C[i * r + j] = s;
+    for (int i = 0; i < p * r; ++i) C[i] = 0.0;
+    for (int k = 0; k < q; ++k)
+        for (int i = 0; i < p; ++i) {
+            const double a = A[k * p + i];
+            for (int j = 0; j < r; ++j) C[i * r + j] += a * B[k * r + j];
         }
 }
 /* C[p x r] = A[p x q] * B[q x r] */
 static void ab(const double *A, const double *B, double *C, int p, int q, int r) {
-    for (int i = 0; i < p; ++i)
-        for (int j = 0; j < r; ++j) {
-            double s = 0.0;
-            for (int k = 0; k < q; ++k) s += A[i * q + k] * B[k * r + j];
-            C[i * r + j] = s;
+    for (int i = 0; i < p; ++i) {
+        for (int j = 0; j < r; ++j) C[i * r + j] = 0.0;
+        for (int k = 0; k < q; ++k) {
+            const double a = A[i * q + k];
+            for (int j = 0; j < r; ++j) C[i * r + j] += a * B[k * r + j];
         }
+    }
 }
 /* Solve S X = Y in place (S m x m, Y m x n): LU with partial pivoting (first max wins, as
  * LAPACK idamax), forward elimination applied to Y, then back substitution. */

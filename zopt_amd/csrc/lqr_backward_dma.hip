@@ -216,6 +216,9 @@ __global__ __launch_bounds__(64, 4) void lqr_backward_dma_f64(const double* __re
                 b[i] = exch[i * 16 + c];
             }
             const double ybt = *(const double*)(lds + oYBr);
+            // The solve is a long chain of short dependent VALU ops; without priority each of them can queue behind a
+            // 64-cycle MFMA of another wave on the shared fp64 pipe (measured: -3..4 % kernel time).
+            __builtin_amdgcn_s_setprio(3);
             if (!__all(lu_solve4_nopivot(S, b, x))) {
                 // rare: growth check failed somewhere in the wave -> partial pivoting, IEEE division
                 lu_solve4(S, b, x);
@@ -225,6 +228,7 @@ __global__ __launch_bounds__(64, 4) void lqr_backward_dma_f64(const double* __re
             const double x23 = (g & 1) ? x[3] : x[2];
             const double lv = (g & 2) ? x23 : x01;  // L_k[g][c]
             const double ln = -lv;
+            __builtin_amdgcn_s_setprio(0);
             if (vL) *pL = lv;
             pL -= nm;
 
