@@ -53,6 +53,21 @@ int zm_lqr_backward_f64(const double* A, const double* B, const double* Q, const
 int zm_lqr_backward_host_f64(const double* A, const double* B, const double* Q, const double* R, double* L,
                              int64_t batch, int T, int n, int m);
 
+/* Batched iLQR backward pass: affine policy (l, L) from the quadratic model along a trajectory.
+ * Replaces: zopt/ilqrUtils.py:153-181  riccatiStep_ilqr / backwardPass_ilqr(dynamics, cost, Vf) -> AffinePolicy
+ *     Q_x = c_x + f_x^T v_x   Q_u = c_u + f_u^T v_x   Q_xx = c_xx + f_x^T v_xx f_x   Q_uu = c_uu + f_u^T v_xx f_u
+ *     Q_ux = c_ux + f_u^T v_xx f_x   l = -solve(Q_uu, Q_u)   L = -solve(Q_uu, Q_ux)                     (:160-168)
+ *     v_x' = Q_x - L^T Q_uu l        v_xx' = Q_xx - L^T Q_uu L                                          (:170)
+ * (the scalar terms c, v and AffineDynamics.f do not influence the returned policy and are not taken)
+ * in : f_x (batch,T,n,n) f_u (batch,T,n,m)                          AffineDynamics   (pytrees.py:129-136)
+ *      c_x (batch,T,n) c_u (batch,T,m) c_xx (batch,T,n,n) c_ux (batch,T,m,n) c_uu (batch,T,m,m)   QuadraticCostFunction (:84-98)
+ *      vf_x (batch,n) vf_xx (batch,n,n)                             QuadraticValueFunction Vf (:58-69)
+ * out: l (batch,T,m)  L (batch,T,m,n)                               AffinePolicy (:207-213), u = alpha*l + L dx + uPrev
+ */
+int zm_ilqr_backward_f64(const double* f_x, const double* f_u, const double* c_x, const double* c_u,
+                         const double* c_xx, const double* c_ux, const double* c_uu, const double* vf_x,
+                         const double* vf_xx, double* l, double* L, int64_t batch, int T, int n, int m, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,3 +43,27 @@ def random_time_varying(batch: int, T: int, n: int, m: int, seed: int = 0, dtype
     Q = M @ np.swapaxes(M, -1, -2) / n + np.eye(n)
     R = N @ np.swapaxes(N, -1, -2) / m + np.eye(m)
     return A.astype(dtype), B.astype(dtype), Q.astype(dtype), R.astype(dtype)
+
+
+def random_ilqr_model(batch: int, T: int, n: int, m: int, seed: int = 0):
+    """Random quadratic model along a trajectory for the iLQR backward pass: (AffineDynamics, QuadraticCost, Vf) fields.
+
+    f_x ~ contraction-ish, f_u ~ N(0,1); stacked cost Hessian H = M M^T/(n+m) + I (positive definite); random
+    gradients; terminal v_xx = M M^T/n + I."""
+    rng = np.random.default_rng(seed)
+    f = rng.standard_normal((batch, T, n))
+    f_x = rng.standard_normal((batch, T, n, n)) * (0.9 / np.sqrt(n))
+    f_u = rng.standard_normal((batch, T, n, m))
+    M = rng.standard_normal((batch, T, n + m, n + m))
+    H = M @ np.swapaxes(M, -1, -2) / (n + m) + np.eye(n + m)
+    c = rng.standard_normal((batch, T))
+    c_x = rng.standard_normal((batch, T, n))
+    c_u = rng.standard_normal((batch, T, m))
+    c_xx = np.ascontiguousarray(H[..., :n, :n])
+    c_ux = np.ascontiguousarray(H[..., n:, :n])
+    c_uu = np.ascontiguousarray(H[..., n:, n:])
+    Mv = rng.standard_normal((batch, n, n))
+    v_xx = Mv @ np.swapaxes(Mv, -1, -2) / n + np.eye(n)
+    v_x = rng.standard_normal((batch, n))
+    v = rng.standard_normal(batch)
+    return (f, f_x, f_u), (c, c_x, c_u, c_xx, c_ux, c_uu), (v, v_x, v_xx)

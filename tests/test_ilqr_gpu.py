@@ -1,0 +1,109 @@
+"""GPU parity tests for K3 ilqr_backward (backwardPass_ilqr, reference ilqrUtils.py:153-181).
+
+zopt_amd.ilqrUtils -> ctypes -> C ABI -> HIP kernel; the NumPy oracle is only the checker.
+Tolerance (fp64): max|err| <= 1e-10 * max|ref| on l and L (measured ~1e-14)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import zopt_oracle as zo
+from tests import problems
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def ilqr():
+    import torch
+    assert torch.cuda.is_available()
+    from zopt_amd import ilqrUtils
+    return ilqrUtils
+
+
+def test_kat_riccati_step(ilqr):
+    """reference tests/test_ilqrUtils.py:56-81 as a 1-step backward pass: l = 0, L = -0.5 I (exact)."""
+    from zopt_amd import pytrees as pt
+    I2 = np.eye(2)
+    dyn = pt.AffineDynamics(np.zeros((1, 2)), I2[None], I2[None])
+    cost = pt.QuadraticCostFunction(np.zeros(1), np.zeros((1, 2)), np.zeros((1, 2)), I2[None], np.zeros((1, 2, 2)), I2[None])
+    Vf = pt.QuadraticValueFunction(0.0, np.zeros(2), I2)
+    pol = ilqr.backwardPass_ilqr(dyn, cost, Vf)
+    assert isinstance(pol, pt.AffinePolicy)
+    assert np.all(pol.l[0] == np.array(KATS["A3_riccatiStep_ilqr"]["l"]))
+    assert np.all(pol.L[0] == np.array(KATS["A3_riccatiStep_ilqr"]["L"]))
+
+
+def test_kat_two_step_identity(ilqr):
+    """reference tests/test_ilqrUtils.py:84-107 inputs (N=2 identities): hand-derived Riccati values L[1]=-0.5 I, L[0]=-0.6 I."""
+    from zopt_amd import pytrees as pt
+    N = 2
+    I = np.repeat(np.eye(2)[None], N, axis=0)
+    pol = ilqr.backwardPass_ilqr(pt.AffineDynamics(np.zeros((N, 2)), I, I),
+                                 pt.QuadraticCostFunction(np.zeros(N), np.zeros((N, 2)), np.zeros((N, 2)), I,
+                                                          np.zeros((N, 2, 2)), I),
+                                 pt.QuadraticValueFunction(0.0, np.zeros(2), np.eye(2)))
+    assert pol.L[1] == pytest.approx(-0.5 * np.eye(2), rel=1e-14)
+    assert pol.L[0] == pytest.approx(-0.6 * np.eye(2), rel=1e-14)
+    assert np.all(pol.l == 0)
+
+
+@pytest.mark.parametrize("n,m,T,batch", [
+    (12, 4, 100, 16),   # BASELINE config 4 shape (quadcopter n=12, m=4, T=100)
+    (12, 4, 30, 5), (8, 4, 10, 3), (4, 1, 20, 2), (2, 2, 3, 4), (1, 1, 4, 2), (5, 3, 7, 3), (7, 2, 5, 2),
+    (9, 4, 6, 3), (11, 1, 3, 2), (12, 3, 1, 2), (12, 4, 2, 2), (3, 4, 5, 3), (6, 4, 3, 1),
+])
+def test_parity_random_models(ilqr, n, m, T, batch):
+    dyn, cost, Vf = problems.random_ilqr_model(batch, T, n, m, seed=100 * n + 10 * m + T)
+    pol = ilqr.backwardPass_ilqr(dyn, cost, Vf)
+    ref = zo.backwardPass_ilqr(zo.AffineDynamics(*dyn), zo.QuadraticCostFunction(*cost), zo.QuadraticValueFunction(*Vf))
+    assert pol.l.shape == (batch, T, m) and pol.L.shape == (batch, T, m, n)
+    assert _rel(pol.L, ref.L) <= RTOL
+    assert _rel(pol.l, ref.l) <= RTOL
+
+
+def test_reference_shapes_without_batch_axis(ilqr):
+    dyn, cost, Vf = problems.random_ilqr_model(1, 9, 12, 4, seed=3)
+    sq = lambda t: tuple(x[0] for x in t)
+    pol = ilqr.backwardPass_ilqr(sq(dyn), sq(cost), sq(Vf))
+    ref = zo.backwardPass_ilqr(zo.AffineDynamics(*sq(dyn)), zo.QuadraticCostFunction(*sq(cost)),
+                               zo.QuadraticValueFunction(*sq(Vf)))
+    assert pol.L.shape == (9, 4, 12) and pol.l.shape == (9, 4)
+    assert _rel(pol.L, ref.L) <= RTOL and _rel(pol.l, ref.l) <= RTOL
+
+
+def test_lq_problem_equals_riccati(ilqr):
+    """For an LQ problem (cost x'Qx + u'Ru => c_xx = 2Q, c_uu = 2R, quirk Q7) the iLQR gains are minus the LQR gains
+    of discreteFiniteHorizonLqr with terminal value Q (lqrUtils.py:144-173 vs ilqrUtils.py:153-181)."""
+    from zopt_amd import lqrUtils
+    b, T, n, m = 6, 12, 12, 4
+    A, B, Q, R = problems.random_time_varying(b, T + 1, n, m, seed=5)
+    # LQR: stage costs Q[0..T-1], terminal Q[T]  == arrays of length T+1 with B-row T unused by construction below
+    dyn = (np.zeros((b, T, n)), A[:, :T], B[:, :T])
+    cost = (np.zeros((b, T)), np.zeros((b, T, n)), np.zeros((b, T, m)), 2 * Q[:, :T], np.zeros((b, T, m, n)), 2 * R[:, :T])
+    Vf = (np.zeros(b), np.zeros((b, n)), 2 * Q[:, T])
+    pol = ilqr.backwardPass_ilqr(dyn, cost, Vf)
+    ref = zo.backwardPass_ilqr(zo.AffineDynamics(*dyn), zo.QuadraticCostFunction(*cost), zo.QuadraticValueFunction(*Vf))
+    assert _rel(pol.L, ref.L) <= RTOL
+    assert np.max(np.abs(pol.l)) == 0.0
+
+
+def test_pivoting_and_torch(ilqr):
+    import torch
+    dyn, cost, Vf = problems.random_ilqr_model(8, 6, 12, 4, seed=11)
+    c, c_x, c_u, c_xx, c_ux, c_uu = cost
+    P = np.eye(4)[[2, 0, 3, 1]]
+    c_uu = c_uu @ P * 3.0                 # permuted-dominant nonsymmetric: forces the pivoted LU path
+    cost = (c, c_x, c_u, c_xx, c_ux, c_uu)
+    ref = zo.backwardPass_ilqr(zo.AffineDynamics(*dyn), zo.QuadraticCostFunction(*cost), zo.QuadraticValueFunction(*Vf))
+    t = lambda tup: tuple(torch.as_tensor(np.asarray(x), device="cuda") for x in tup)
+    pol = ilqr.backwardPass_ilqr(t(dyn), t(cost), t(Vf))
+    assert pol.L.is_cuda
+    assert _rel(pol.L.cpu().numpy(), ref.L) <= 1e-9 and _rel(pol.l.cpu().numpy(), ref.l) <= 1e-9

@@ -1,0 +1,276 @@
+// K3  ilqr_backward -- batched iLQR backward pass (affine policy from a quadratic value sweep), fp64, gfx950.
+//
+// Replaces the arithmetic of zopt/ilqrUtils.py:153-181 (riccatiStep_ilqr / backwardPass_ilqr), per trajectory,
+// for k = T-1 .. 0 with carry (v_x, v_xx) <- Vf:
+//     Q_x  = c_x  + f_x^T v_x                 Q_u  = c_u  + f_u^T v_x                              (:161-162)
+//     Q_xx = c_xx + f_x^T v_xx f_x   Q_uu = c_uu + f_u^T v_xx f_u   Q_ux = c_ux + f_u^T v_xx f_x    (:163-165)
+//     l = -solve(Q_uu, Q_u)          L = -solve(Q_uu, Q_ux)                                        (:167-168)
+//     v_x' = Q_x - L^T Q_uu l        v_xx' = Q_xx - L^T Q_uu L                                     (:170)
+// The scalar part (c, v) never influences l or L and backwardPass_ilqr returns only the policy, so it is not
+// carried.  `Q_uu l` is taken as -Q_u (its value by construction of l); the difference is the residual of the
+// m x m solve (rounding level).
+//
+// Tile-16 mapping (tile16_f64.h): one wave64 per trajectory, F = [f_x | f_u] as a 16-column tile,
+//     Y = v_xx^T F (KS MFMA),  G = Y^T F + [[c_xx, .],[c_ux, c_uu]] (KS MFMA)  ->  Q_xx (rows < NP), [Q_ux | Q_uu] (row NP+g)
+//     q = [c_x ; c_u] + F^T v_x : 3 FMAs per lane + a 4-group xor reduction (column-indexed, replicated over g)
+//     solve: the 4 x 16 tile [Q_ux | Q_uu] and the row q through LDS; lane c < n solves column c of Q_ux,
+//            lane c == NP solves Q_u.  -x[g] is L_k[g][c] resp. l_k[g].
+//     T1 = Q_uu L (1 MFMA),  v_xx' = Q_xx - L^T T1 (1 MFMA, negated A operand)
+// 2*KS + 2 MFMAs per step.  Inputs are read once with 8-byte loads straight into their register layouts, two steps
+// ahead (register double buffer).  Shapes: n <= 12, m <= 4.
+#include "tile16_f64.h"
+#include "zm_common.h"
+
+namespace zm {
+
+template <int KS>
+struct IlqrStepRegs {
+    double F[KS];   // [f_x | f_u][4s+g][c]
+    double C[KS];   // c_xx[4s+g][c]
+    double Cu;      // row NP+g of the stacked cost Hessian: c_ux[g][c] (c < n) | c_uu[g][c-NP] | identity padding
+    double cv;      // [c_x ; c_u][c]  (column-indexed)
+};
+
+template <int KS>
+struct IlqrAddr {
+    const double* pF0;   // K-step s adds (rowok ? s*dF : 0)
+    const double* pC0;   // K-step s adds (rowok ? s*4n : 0)
+    const double* pCu;
+    const double* pcv;
+    double* pOut;        // L_k[g][c] (c < n) or l_k[g] (c == NP)
+    int dF, dC, sF, sCu, scv, sOut;
+    int nn;
+    bool rowok[KS], vF[KS], vC[KS], vCu, vcv, vOut, vL, cA;
+    double cu_pad;
+};
+
+template <int KS>
+__device__ __forceinline__ void ilqr_load_step(IlqrStepRegs<KS>& d, IlqrAddr<KS>& a) {
+    double f[KS], cc[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) f[s] = a.pF0[a.rowok[s] ? s * a.dF : 0];
+    a.pF0 -= a.sF;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) cc[s] = a.pC0[a.rowok[s] ? s * a.dC : 0];
+    a.pC0 -= a.nn;
+    const double cu = *a.pCu;
+    a.pCu -= a.sCu;
+    const double cv = *a.pcv;
+    a.pcv -= a.scv;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        d.F[s] = a.vF[s] ? f[s] : 0.0;
+        d.C[s] = a.vC[s] ? cc[s] : 0.0;
+    }
+    d.Cu = a.vCu ? cu : a.cu_pad;
+    d.cv = a.vcv ? cv : 0.0;
+}
+
+// LDS per wave (doubles): [0,64) tile rows 0..3 = [Q_ux | Q_uu]; [64,80) row 4 = q; [80,96) v_x' (column-indexed)
+constexpr int ILQR_LDS_DOUBLES = 96;
+
+template <int KS, bool PREFETCH>
+__device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], IlqrStepRegs<KS>& d, IlqrAddr<KS>& a,
+                                          double* sm, const int g, const int c, const int ob0, const int ob1,
+                                          const int ob2, const int ob3, const int oqa) {
+    constexpr int NP = 4 * KS;
+    // Y = v_xx^T F
+    d4 y = zero4();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) y = mfma(Vxx[s], d.F[s], y);
+    // G = Y^T F + C0
+    d4 gacc = zero4();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) gacc[s] = d.C[s];
+    gacc[KS] = d.Cu;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) gacc = mfma(y[s], d.F[s], gacc);
+    // q[c] = cv[c] + sum_k F[k][c] v_x[k]   (partial over this lane's rows, then over the 4 lane groups)
+    double qp = 0.0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qp = __builtin_fma(d.F[s], vxr[s], qp);
+    qp += __shfl_xor(qp, 16);
+    qp += __shfl_xor(qp, 32);
+    const double qv = d.cv + qp;
+    if constexpr (PREFETCH) ilqr_load_step(d, a);
+
+    // solve: tile + q row through LDS
+    sm[g * 16 + c] = gacc[KS];
+    if (g == 0) sm[64 + c] = qv;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double S[4][4], b[4], x[4], qu[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) S[i][jj] = sm[i * 16 + NP + jj];
+        qu[i] = sm[64 + NP + i];  // Q_u (zero beyond m)
+    }
+    b[0] = sm[ob0];
+    b[1] = sm[ob1];
+    b[2] = sm[ob2];
+    b[3] = sm[ob3];
+    const double quu_a = sm[oqa];  // Q_uu[c][g]: A operand of Q_uu L (0-padded through the address choice below)
+    __builtin_amdgcn_wave_barrier();
+    if (!__all(lu_solve4_nopivot(S, b, x))) lu_solve4(S, b, x);
+    const double x01 = (g & 1) ? x[1] : x[0];
+    const double x23 = (g & 1) ? x[3] : x[2];
+    const double out = -((g & 2) ? x23 : x01);  // L_k[g][c] for c < n, l_k[g] for c == NP
+    if (a.vOut) *a.pOut = out;
+    a.pOut -= a.sOut;
+    const double lv = a.vL ? out : 0.0;
+
+    // v_x'[c] = Q_x[c] + sum_i L[i][c] Q_u[i]      (= Q_x - L^T Q_uu l with Q_uu l = -Q_u)
+    double vxn = qv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vxn = __builtin_fma(-x[i], qu[i], vxn);
+    if (g == 0) sm[80 + c] = a.cA ? vxn : 0.0;
+    // T1 = Q_uu L ;  v_xx' = Q_xx - L^T T1
+    const d4 t1 = mfma(quu_a, lv, zero4());
+    d4 vacc = zero4();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) vacc[s] = gacc[s];
+    vacc = mfma<true>(lv, t1[0], vacc);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) Vxx[s] = vacc[s];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int s = 0; s < KS; ++s) vxr[s] = sm[80 + 4 * s + g];
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int KS>
+__global__ __launch_bounds__(64) void ilqr_backward_t16_f64(
+    const double* __restrict__ f_x, const double* __restrict__ f_u, const double* __restrict__ c_x,
+    const double* __restrict__ c_u, const double* __restrict__ c_xx, const double* __restrict__ c_ux,
+    const double* __restrict__ c_uu, const double* __restrict__ vf_x, const double* __restrict__ vf_xx,
+    double* __restrict__ lout, double* __restrict__ Lout, const int T, const int n, const int m) {
+    constexpr int NP = 4 * KS;
+    const int lane = threadIdx.x;
+    const long traj = blockIdx.x;
+    const int g = lane >> 4, c = lane & 15;
+    __shared__ double sm[ILQR_LDS_DOUBLES];
+
+    IlqrAddr<KS> a;
+    const int nn = n * n, nm = n * m, mm = m * m;
+    a.nn = nn;
+    const bool cA = c < n;
+    a.cA = cA;
+    const bool cB = (c >= NP) && (c < NP + m);
+    const long last = traj * T + (T - 1);
+    const double* fxt = f_x + last * nn;
+    const double* fut = f_u + last * nm;
+    const double* cxt = c_x + last * n;
+    const double* cut = c_u + last * m;
+    const double* cxxt = c_xx + last * nn;
+    const double* cuxt = c_ux + last * nm;
+    const double* cuut = c_uu + last * mm;
+    const bool row0 = g < n;
+    const bool laneA = row0 && cA, laneB = row0 && cB;
+    a.dF = laneA ? 4 * n : laneB ? 4 * m : 0;
+    a.sF = laneB ? nm : nn;
+    a.dC = laneA ? 4 * n : 0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int row = 4 * s + g;
+        a.rowok[s] = row < n;
+        a.vF[s] = (row < n) && (cA || cB);
+        a.vC[s] = (row < n) && cA;
+    }
+    a.pF0 = laneA ? (fxt + g * n + c) : laneB ? (fut + g * m + (c - NP)) : fxt;
+    a.pC0 = laneA ? (cxxt + g * n + c) : cxxt;
+    // row NP+g of the stacked Hessian: c_ux[g][c] under the state columns, c_uu[g][c-NP] under the control columns
+    const bool vux = (g < m) && cA, vuu = (g < m) && cB;
+    a.vCu = vux || vuu;
+    a.pCu = vux ? (cuxt + g * n + c) : vuu ? (cuut + g * m + (c - NP)) : cuxt;
+    a.sCu = vuu ? mm : nm;
+    a.cu_pad = (g >= m && c == NP + g) ? 1.0 : 0.0;
+    a.vcv = cA || cB;
+    a.pcv = cA ? (cxt + c) : cB ? (cut + (c - NP)) : cxt;
+    a.scv = cB ? m : n;
+    a.vL = (g < m) && cA;
+    const bool vl = (g < m) && (c == NP);
+    a.vOut = a.vL || vl;
+    a.pOut = a.vL ? (Lout + last * nm + g * n + c) : (lout + last * m + g);
+    a.sOut = vl ? m : nm;
+
+    // LDS addresses of this lane's right-hand side: column c of [Q_ux | .] for c < n, the row q (Q_u) for c == NP
+    const bool rhs_qu = (c == NP);
+    const int ob0 = rhs_qu ? (64 + NP + 0) : (0 * 16 + c);
+    const int ob1 = rhs_qu ? (64 + NP + 1) : (1 * 16 + c);
+    const int ob2 = rhs_qu ? (64 + NP + 2) : (2 * 16 + c);
+    const int ob3 = rhs_qu ? (64 + NP + 3) : (3 * 16 + c);
+    // Q_uu[c][g] as A operand (c < 4): tile row c, column NP+g.  Lanes c >= 4 only feed output rows >= 4 of
+    // Q_uu L, which are never used: they read their own (finite) tile element.
+    const int oqa = (c < 4) ? (c * 16 + NP + g) : (g * 16 + c);
+
+    // terminal value function
+    double Vxx[KS], vxr[KS];
+    {
+        const double* vxx = vf_xx + traj * nn;
+        const double* vx = vf_x + traj * n;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int row = 4 * s + g;
+            const bool ok = (row < n) && cA;
+            const double t = vxx[ok ? row * n + c : 0];
+            Vxx[s] = ok ? t : 0.0;
+            const double u = vx[row < n ? row : 0];
+            vxr[s] = (row < n) ? u : 0.0;
+        }
+    }
+
+    IlqrStepRegs<KS> d0, d1;
+    ilqr_load_step(d0, a);
+    if (T >= 2) ilqr_load_step(d1, a);
+    int k = T - 1;
+    while (k >= 3) {
+        ilqr_step<KS, true>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
+        ilqr_step<KS, true>(Vxx, vxr, d1, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
+        k -= 2;
+    }
+    if (k == 2) {
+        ilqr_step<KS, true>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
+        ilqr_step<KS, false>(Vxx, vxr, d1, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
+        ilqr_step<KS, false>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
+    } else if (k == 1) {
+        ilqr_step<KS, false>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
+        ilqr_step<KS, false>(Vxx, vxr, d1, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
+    } else {
+        ilqr_step<KS, false>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
+    }
+}
+
+}  // namespace zm
+
+extern "C" int zm_ilqr_backward_f64(const double* f_x, const double* f_u, const double* c_x, const double* c_u,
+                                    const double* c_xx, const double* c_ux, const double* c_uu, const double* vf_x,
+                                    const double* vf_xx, double* l, double* L, int64_t batch, int T, int n, int m,
+                                    void* stream) {
+    if (!f_x || !f_u || !c_x || !c_u || !c_xx || !c_ux || !c_uu || !vf_x || !vf_xx || !l || !L)
+        return zm::set_error(ZM_EINVAL, "zm_ilqr_backward_f64: null pointer");
+    if (batch < 0 || T < 1 || n < 1 || m < 1)
+        return zm::set_error(ZM_EINVAL, "zm_ilqr_backward_f64: bad size batch=%lld T=%d n=%d m=%d", (long long)batch, T,
+                             n, m);
+    if (n > 12 || m > 4)
+        return zm::set_error(ZM_EUNSUPPORTED, "zm_ilqr_backward_f64: (n=%d, m=%d) not covered (need n<=12, m<=4)", n, m);
+    if ((int64_t)T * n * n >= (int64_t)1 << 31 || batch >= ((int64_t)1 << 31))
+        return zm::set_error(ZM_EUNSUPPORTED, "zm_ilqr_backward_f64: T*n*n or batch too large");
+    if (batch == 0) return ZM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)batch), block(64);
+    if (n <= 4)
+        hipLaunchKernelGGL((zm::ilqr_backward_t16_f64<1>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
+                           vf_xx, l, L, T, n, m);
+    else if (n <= 8)
+        hipLaunchKernelGGL((zm::ilqr_backward_t16_f64<2>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
+                           vf_xx, l, L, T, n, m);
+    else
+        hipLaunchKernelGGL((zm::ilqr_backward_t16_f64<3>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
+                           vf_xx, l, L, T, n, m);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
