@@ -155,12 +155,12 @@ def main():
 
     gather_ms = None
     if args.gather and world > 1:
-        out = torch.empty((world,) + tuple(L.shape), dtype=L.dtype, device=dev)
-        dist.all_gather_into_tensor(out, L)
+        from zopt_amd import dist as zdist
+        zdist.allgather_results(L, world * batch)      # warm-up (RCCL communicator setup)
         torch.cuda.synchronize()
         barrier()
         g0 = time.perf_counter()
-        dist.all_gather_into_tensor(out, L)
+        zdist.allgather_results(L, world * batch)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
 

@@ -68,6 +68,39 @@ int zm_ilqr_backward_f64(const double* f_x, const double* f_u, const double* c_x
                          const double* c_xx, const double* c_ux, const double* c_uu, const double* vf_x,
                          const double* vf_xx, double* l, double* L, int64_t batch, int T, int n, int m, void* stream);
 
+/* ---- registered device models (the reference differentiates / rolls out arbitrary Python callables with JAX;
+ *      a kernel needs the model in device code) ------------------------------------------------------------------ */
+#define ZM_MODEL_LINEAR 1     /* x+ = A x + B u, A (n,n), B (n,m) device pointers shared by the whole batch           */
+#define ZM_MODEL_QUADCOPTER 2 /* x+ = x + dt * Quadcopter.inertialDynamics(x,u)  (zopt/quadcopter.py:116-144), n=12, m=4 */
+typedef struct zm_model_t {
+    int kind, n, m, reserved;
+    double dt;              /* quadcopter: Euler step (demos/iterativeLqr.py:23,35) */
+    const double* A;        /* linear: device pointers; else NULL */
+    const double* B;
+} zm_model_t;
+
+/* c(x,u) = x^T Q x + u^T R u,  c_f(x) = x^T Qf x  (demos/iterativeLqr.py:12-13,37; no 1/2).  Device pointers. */
+typedef struct zm_quadcost_t {
+    const double* Q;        /* (n,n) */
+    const double* R;        /* (m,m) */
+    const double* Qf;       /* (n,n) */
+} zm_quadcost_t;
+
+/* Batched policy rollout with a parallel line search over step sizes.
+ * Replaces: zopt/ilqrUtils.py:33-66 trajectoryRollout (n_alpha = 1, cost may be NULL) and :116-150 forwardPass2
+ *           (n_alpha = 16, alphas = 0.5^j), with AffinePolicy.__call__ (pytrees.py:215-220) and CostFunction.__call__
+ *           (pytrees.py:49-52):
+ *     for each alpha:  x_0 = x0;  u_k = alpha*l_k + L_k (x_k - xPrev_k) + uPrev_k;  x_{k+1} = f(x_k, u_k)
+ *                      J = sum_k c(x_k,u_k) + c_f(x_T);        result = the rollout with the smallest J (NaN wins, as argmin)
+ * in : x0 (batch,n)  l (batch,T,m)  L (batch,T,m,n)  xPrev (batch,T+1,n)  uPrev (batch,T,m)  alphas (n_alpha) [device]
+ *      active (batch) int32 or NULL: trajectories with active==0 are skipped (their outputs are left untouched)
+ * out: xTraj (batch,T+1,n)  uTraj (batch,T,m)  J (batch) or NULL  alpha_idx (batch) int32 or NULL
+ */
+int zm_rollout_linesearch_f64(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0, const double* l,
+                              const double* L, const double* xPrev, const double* uPrev, const double* alphas,
+                              int n_alpha, const int32_t* active, double* xTraj, double* uTraj, double* J,
+                              int32_t* alpha_idx, int64_t batch, int T, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -332,3 +332,77 @@ def forwardPass2(x0, dynFun, runningCost, terminalCost, policy, trajPrev):
         Js.append(trajectoryCost(runningCost, terminalCost, t))
     idx = int(np.argmin(np.asarray(Js)))
     return trajs[idx], Js[idx]
+
+
+# ----------------------------------------------------------------------------------------
+# A10  Quadcopter model                                   reference quadcopter.py:10-144
+# ----------------------------------------------------------------------------------------
+QUAD_G = 9.807          # quadcopter.py:15
+QUAD_MASS = 2.5         # :16
+QUAD_FORCE_LIN = np.array([-0.2, -0.2, -0.3])      # :59
+QUAD_FORCE_QUAD = np.array([-0.05, -0.05, -0.1])   # :60
+QUAD_MOMENT_LIN = np.array([-0.1, -0.1, -0.05])    # :61
+
+
+def quad_bodyToInertialRotationMatrix(phi, theta, psi):
+    """quadcopter.py:23-38, reproduced as written (quirk Q4: entry [0][2] is cphi*sth*cpsi - sphi*spsi)."""
+    cphi, sphi = np.cos(phi), np.sin(phi)
+    cth, sth = np.cos(theta), np.sin(theta)
+    cpsi, spsi = np.cos(psi), np.sin(psi)
+    return np.array([
+        [cth * cpsi, sphi * sth * cpsi - cphi * spsi, cphi * sth * cpsi - sphi * spsi],
+        [cth * spsi, sphi * sth * spsi + cphi * cpsi, cphi * sth * spsi - sphi * cpsi],
+        [-sth, sphi * cth, cphi * cth],
+    ])
+
+
+def quad_bodyRatesToEulerRatesRotationMatrix(phi, theta):
+    """quadcopter.py:41-48."""
+    sphi, cphi = np.sin(phi), np.cos(phi)
+    cth, tth = np.cos(theta), np.tan(theta)
+    return np.array([[1, sphi * tth, cphi * tth], [0, cphi, -sphi], [0, sphi / cth, cphi / cth]])
+
+
+def quad_rigidBodyDynamics(state, control, wind_body=np.zeros(3)):
+    """quadcopter.py:70-113: state [u,v,w,p,q,r,phi,theta(,...)] -> 8 derivatives (quirk Q5: reads only [0:8])."""
+    state = np.asarray(state, dtype=np.float64)
+    control = np.asarray(control, dtype=np.float64)
+    uvw, pqr = state[0:3], state[3:6]
+    phi, theta = state[6:8]
+    thrust, mxyz = control[0], control[1:4]
+    d2xyz = np.array([-np.sin(theta), np.sin(phi) * np.cos(theta), np.cos(phi) * np.cos(theta)])
+    R_rates2Eul = quad_bodyRatesToEulerRatesRotationMatrix(phi, theta)
+    uvw_aero = uvw - wind_body                                                        # :64
+    force_aero = QUAD_FORCE_LIN * uvw_aero + QUAD_FORCE_QUAD * uvw_aero ** 2         # :65
+    moment_aero = QUAD_MOMENT_LIN * pqr                                               # :66
+    force_total = QUAD_MASS * np.array([0, 0, -thrust]) + force_aero + QUAD_MASS * QUAD_G * d2xyz   # :98-100
+    moment_total = mxyz + moment_aero                                                 # :102-103 (I = eye(3))
+    uvwDot = (1 / QUAD_MASS) * (-np.cross(pqr, uvw) + force_total)                    # :106
+    pqrDot = -np.cross(pqr, pqr) + moment_total                                       # :107
+    phiThetaDot = R_rates2Eul[0:2, :] @ pqr                                           # :108
+    return np.concatenate([uvwDot, pqrDot, phiThetaDot])
+
+
+def quad_inertialDynamics(state, control, wind_ned=np.zeros(3)):
+    """quadcopter.py:116-144: 12-state xDot = f(x, u); state [u,v,w,p,q,r,phi,theta,psi,x,y,z]."""
+    state = np.asarray(state, dtype=np.float64)
+    uvw, pqr = state[0:3], state[3:6]
+    phi, theta, psi = state[6:9]
+    R_b2i = quad_bodyToInertialRotationMatrix(phi, theta, psi)
+    R_rates2Eul = quad_bodyRatesToEulerRatesRotationMatrix(phi, theta)
+    wind_body = R_b2i.T @ wind_ned
+    xDot_rb = quad_rigidBodyDynamics(state[:9], control, wind_body=wind_body)
+    psiDot = np.array([R_rates2Eul[2, :] @ pqr])
+    xyzDot = R_b2i @ uvw
+    return np.concatenate([xDot_rb, psiDot, xyzDot])
+
+
+def quad_euler_step(dt):
+    """The discrete map of the iLQR / DDP / MPC demos: x+ = x + dt * inertialDynamics(x, u) (demos/iterativeLqr.py:35)."""
+    return lambda x, u: x + dt * quad_inertialDynamics(x, u)
+
+
+def quadratic_costs(Q, R, Qf):
+    """runningCost = x'Qx + u'Ru, terminalCost = x'Qf x (demos/iterativeLqr.py:12-13,37; no 1/2, quirk Q7)."""
+    Q, R, Qf = (np.asarray(t, dtype=np.float64) for t in (Q, R, Qf))
+    return (lambda x, u: x @ Q @ x + u @ R @ u), (lambda x: x @ Qf @ x)

@@ -163,3 +163,28 @@ def test_batch_axes_equal_loop_over_trajectories():
     for i in range(4):
         Li = zo.discreteFiniteHorizonLqr(A[i], B[i], Q[i], R[i], 10)
         assert np.allclose(Li, Lb[i], rtol=1e-13, atol=1e-15)
+
+
+def test_kat_quadcopter_model():
+    """reference tests/test_quadcopter.py:12-86 (rotation matrices, rigid-body and inertial dynamics)."""
+    assert zo.quad_bodyToInertialRotationMatrix(0, 0, 0) == pytest.approx(np.eye(3))
+    th = np.pi / 6
+    cth, sth, tth = np.cos(th), np.sin(th), np.tan(th)
+    assert zo.quad_bodyToInertialRotationMatrix(th, 0, 0) == pytest.approx(np.array([[1, 0, 0], [0, cth, -sth], [0, sth, cth]]))
+    assert zo.quad_bodyToInertialRotationMatrix(0, th, 0) == pytest.approx(np.array([[cth, 0, sth], [0, 1, 0], [-sth, 0, cth]]))
+    assert zo.quad_bodyToInertialRotationMatrix(0, 0, th) == pytest.approx(np.array([[cth, -sth, 0], [sth, cth, 0], [0, 0, 1]]))
+    assert zo.quad_bodyRatesToEulerRatesRotationMatrix(0, 0) == pytest.approx(np.eye(3))
+    assert zo.quad_bodyRatesToEulerRatesRotationMatrix(th, 0) == pytest.approx(np.array([[1, 0, 0], [0, cth, -sth], [0, sth, cth]]))
+    assert zo.quad_bodyRatesToEulerRatesRotationMatrix(0, th) == pytest.approx(np.array([[1, 0, tth], [0, 1, 0], [0, 0, 1 / cth]]))
+    k = KATS["A10_quadcopter"]
+    assert zo.quad_rigidBodyDynamics(np.zeros(9), np.zeros(4)) == pytest.approx(np.array(k["rigidBody_rest_zero_thrust"]["xDot"]))
+    hover = np.array([9.807, 0, 0, 0])
+    assert zo.quad_rigidBodyDynamics(np.zeros(9), hover) == pytest.approx(np.zeros(8))
+    assert zo.quad_inertialDynamics(np.zeros(12), hover) == pytest.approx(np.zeros(12))
+    s = np.zeros(12); s[0:3] = [0.1, 0.2, 0.3]
+    assert zo.quad_inertialDynamics(s, hover)[9:] == pytest.approx(np.array([0.1, 0.2, 0.3]))
+    s[8] = np.pi / 2
+    assert zo.quad_inertialDynamics(s, hover)[9:] == pytest.approx(np.array([-0.2, 0.1, 0.3]))
+    # quirk Q4 is reproduced: entry [0][2] of the body-to-inertial matrix for a general attitude
+    R = zo.quad_bodyToInertialRotationMatrix(0.3, 0.2, 0.1)
+    assert R[0, 2] == pytest.approx(np.cos(0.3) * np.sin(0.2) * np.cos(0.1) - np.sin(0.3) * np.sin(0.1))

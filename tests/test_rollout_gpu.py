@@ -1,0 +1,173 @@
+"""GPU parity tests for K6 rollout_linesearch (trajectoryRollout / forwardPass2, reference ilqrUtils.py:33-66, 116-150).
+
+Tolerance: trajectories are T-step recursions through the model; device sin/cos/tan differ from libm by <= a few ulp,
+so max|err| <= 1e-9 * max|ref| (measured ~1e-13) and J to 1e-10 relative."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import zopt_oracle as zo
+
+pytestmark = pytest.mark.gpu
+KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
+
+
+def _rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import torch
+    assert torch.cuda.is_available()
+    from zopt_amd import ilqrUtils, models, pytrees
+    return ilqrUtils, models, pytrees
+
+
+def test_kat_trajectoryRollout(mods):
+    """reference tests/test_ilqrUtils.py:7-22: dynFun = x+u, policy = alpha*k, zero previous trajectory; exact."""
+    ilqr, models, pt = mods
+    k = KATS["A6_trajectoryRollout"]
+    N = k["N"]
+    model = models.LinearModel(np.eye(1), np.eye(1))
+    policy = pt.AffinePolicy(np.arange(N, dtype=np.float64)[:, None], np.zeros((N, 1, 1)))
+    trajPrev = pt.Trajectory(np.zeros((N + 1, 1)), np.zeros((N, 1)))
+    x0 = np.array(k["x0"])
+    t = ilqr.trajectoryRollout(x0, model, policy, trajPrev)
+    assert np.all(t.xTraj == np.array(k["alpha1"]["xTraj"])[:, None])
+    assert np.all(t.uTraj == np.array(k["alpha1"]["uTraj"])[:, None])
+    t = ilqr.trajectoryRollout(x0, model, policy, trajPrev, alpha=0.5)
+    assert np.all(t.xTraj == np.array(k["alpha0.5"]["xTraj"])[:, None])
+    assert np.all(t.uTraj == np.array(k["alpha0.5"]["uTraj"])[:, None])
+
+
+def _random_policy_problem(rng, batch, N, n, m, x_scale=1.0):
+    l = 0.3 * rng.standard_normal((batch, N, m))
+    L = 0.2 * rng.standard_normal((batch, N, m, n)) / np.sqrt(n)
+    xPrev = x_scale * rng.standard_normal((batch, N + 1, n))
+    uPrev = 0.3 * rng.standard_normal((batch, N, m))
+    x0 = x_scale * rng.standard_normal((batch, n))
+    return x0, l, L, xPrev, uPrev
+
+
+@pytest.mark.parametrize("n,m,N,batch", [(12, 4, 30, 9), (2, 2, 3, 5), (4, 1, 50, 3), (8, 4, 20, 70), (5, 3, 7, 2), (1, 1, 4, 1)])
+def test_linear_model_rollout_parity(mods, n, m, N, batch):
+    ilqr, models, pt = mods
+    rng = np.random.default_rng(100 * n + m)
+    A = rng.standard_normal((n, n)) * (0.9 / np.sqrt(n))
+    B = rng.standard_normal((n, m))
+    model = models.LinearModel(A, B)
+    x0, l, L, xPrev, uPrev = _random_policy_problem(rng, batch, N, n, m)
+    for alpha in (1, 0.25):
+        t = ilqr.trajectoryRollout(x0, model, pt.AffinePolicy(l, L), pt.Trajectory(xPrev, uPrev), alpha=alpha)
+        assert t.xTraj.shape == (batch, N + 1, n) and t.uTraj.shape == (batch, N, m)
+        for b in range(batch):
+            r = zo.trajectoryRollout(x0[b], model, zo.AffinePolicy(l[b], L[b]), zo.Trajectory(xPrev[b], uPrev[b]), alpha=alpha)
+            assert _rel(t.xTraj[b], r.xTraj) <= 1e-11 and _rel(t.uTraj[b], r.uTraj) <= 1e-11
+
+
+def _quad_problem(rng, batch, N):
+    """Small perturbations around hover: the open-loop quadcopter is unstable (and its quadratic drag blows up in finite
+    time for large negative speeds), so keep the excursion moderate over the horizon."""
+    x0, l, L, xPrev, uPrev = _random_policy_problem(rng, batch, N, 12, 4, x_scale=0.05)
+    l, L = 0.05 * l, 0.1 * L
+    uPrev = 0.1 * uPrev + np.array([9.807, 0, 0, 0])   # around hover
+    return x0, l, L, xPrev, uPrev
+
+
+def test_quadcopter_rollout_parity(mods):
+    """Device restatement of quadcopter.py:116-144 (incl. quirk Q4) + Euler step vs the NumPy oracle, T = 60 (excursions up to |x| ~ 25)."""
+    ilqr, models, pt = mods
+    rng = np.random.default_rng(7)
+    batch, N = 6, 60
+    x0, l, L, xPrev, uPrev = _quad_problem(rng, batch, N)
+    model = models.QuadcopterEuler(dt=0.1)
+    step = zo.quad_euler_step(0.1)
+    t = ilqr.trajectoryRollout(x0, model, pt.AffinePolicy(l, L), pt.Trajectory(xPrev, uPrev), alpha=0.5)
+    for b in range(batch):
+        r = zo.trajectoryRollout(x0[b], step, zo.AffinePolicy(l[b], L[b]), zo.Trajectory(xPrev[b], uPrev[b]), alpha=0.5)
+        assert np.all(np.isfinite(r.xTraj))
+        assert _rel(t.xTraj[b], r.xTraj) <= 1e-9 and _rel(t.uTraj[b], r.uTraj) <= 1e-9
+
+
+def test_quadcopter_model_known_answers_on_device(mods):
+    """reference tests/test_quadcopter.py:62-86 through a 1-step rollout: x1 = x0 + dt*f(x0,u0)."""
+    ilqr, models, pt = mods
+    dt = 0.1
+    hover = np.array([9.807, 0, 0, 0.0])
+    states = np.zeros((3, 12))
+    states[1, 0:3] = [0.1, 0.2, 0.3]
+    states[2, 0:3] = [0.1, 0.2, 0.3]
+    states[2, 8] = np.pi / 2
+    pol = pt.AffinePolicy(np.zeros((3, 1, 4)), np.zeros((3, 1, 4, 12)))
+    prev = pt.Trajectory(np.zeros((3, 2, 12)), np.tile(hover, (3, 1, 1)))
+    t = ilqr.trajectoryRollout(states, models.QuadcopterEuler(dt), pol, prev)
+    xdot = (t.xTraj[:, 1] - states) / dt
+    assert xdot[0] == pytest.approx(np.zeros(12), abs=1e-12)                    # hover: no motion
+    assert xdot[1, 9:] == pytest.approx(np.array([0.1, 0.2, 0.3]), rel=1e-12)   # no rotation
+    assert xdot[2, 9:] == pytest.approx(np.array([-0.2, 0.1, 0.3]), rel=1e-12)  # psi = 90 deg
+
+
+@pytest.mark.parametrize("kind", ["linear", "quadcopter"])
+def test_forwardPass2_parity(mods, kind):
+    ilqr, models, pt = mods
+    rng = np.random.default_rng(11)
+    batch, N = 10, 25
+    if kind == "linear":
+        n, m = 12, 4
+        model = models.LinearModel(rng.standard_normal((n, n)) * (1.05 / np.sqrt(n)), rng.standard_normal((n, m)))
+        x0, l, L, xPrev, uPrev = _random_policy_problem(rng, batch, N, n, m)
+        l *= 4.0      # big steps: smaller alphas must win for some trajectories
+        f = model
+    else:
+        n, m = 12, 4
+        model = models.QuadcopterEuler(0.1)
+        x0, l, L, xPrev, uPrev = _quad_problem(rng, batch, N)
+        l *= 60.0     # big feed-forward steps: smaller alphas must win for some trajectories
+        f = zo.quad_euler_step(0.1)
+    Mq = rng.standard_normal((n, n)); Mr = rng.standard_normal((m, m))
+    cost = models.QuadraticCost(Mq @ Mq.T / n + np.eye(n), Mr @ Mr.T / m + np.eye(m), 10 * np.eye(n))
+    traj, J = ilqr.forwardPass2(x0, model, cost, pt.AffinePolicy(l, L), pt.Trajectory(xPrev, uPrev))
+    assert J.shape == (batch,)
+    picked = set()
+    for b in range(batch):
+        rt, rJ = zo.forwardPass2(x0[b], f, cost.runningCost, cost.terminalCost, zo.AffinePolicy(l[b], L[b]),
+                                 zo.Trajectory(xPrev[b], uPrev[b]))
+        assert abs(J[b] - rJ) <= 1e-10 * abs(rJ)
+        assert _rel(traj.xTraj[b], rt.xTraj) <= 1e-9 and _rel(traj.uTraj[b], rt.uTraj) <= 1e-9
+        picked.add(round(float(np.max(np.abs(rt.uTraj - uPrev[b]))), 6))
+    assert len(picked) > 1
+
+
+def test_nan_wins_argmin(mods):
+    """jnp.argmin / np.argmin treat NaN as the minimum: the first NaN cost wins the line search (ilqrUtils.py:147),
+    even against -inf.  alpha = 1 drives the state to (-inf, +inf) -> x'Qx = inf - inf = NaN; smaller steps give -inf."""
+    ilqr, models, pt = mods
+    n = m = 2
+    model = models.LinearModel(np.array([[1.0, -1.0], [0.0, 1.0]]), np.eye(2))
+    cost = models.QuadraticCost(np.zeros((2, 2)), np.zeros((2, 2)), np.diag([1.0, -1.0]))
+    N = 3
+    l = np.full((1, N, m), 1.5e308)
+    L = np.zeros((1, N, m, n))
+    prev = pt.Trajectory(np.zeros((1, N + 1, n)), np.zeros((1, N, m)))
+    x0 = np.zeros((1, n))
+    traj, J = ilqr.forwardPass2(x0, model, cost, pt.AffinePolicy(l, L), prev)
+    with np.errstate(all="ignore"):
+        Js = [zo.trajectoryCost(cost.runningCost, cost.terminalCost,
+                                zo.trajectoryRollout(x0[0], model, zo.AffinePolicy(l[0], L[0]),
+                                                     zo.Trajectory(prev.xTraj[0], prev.uTraj[0]), alpha=a))
+              for a in zo.LINESEARCH_ALPHAS]
+        rt, rJ = zo.forwardPass2(x0[0], model, cost.runningCost, cost.terminalCost, zo.AffinePolicy(l[0], L[0]),
+                                 zo.Trajectory(prev.xTraj[0], prev.uTraj[0]))
+    assert np.isnan(Js[0]) and (-np.inf in Js)           # the construction really has NaN competing with -inf
+    assert np.isnan(rJ) and np.isnan(J[0])
+    assert np.array_equal(traj.uTraj[0], rt.uTraj)       # alpha = 1 (index 0)
+
+
+def test_unregistered_callable_is_rejected(mods):
+    ilqr, models, pt = mods
+    with pytest.raises(TypeError):
+        ilqr.trajectoryRollout(np.zeros(1), lambda x, u: x + u, pt.AffinePolicy(np.zeros((1, 1)), np.zeros((1, 1, 1))),
+                               pt.Trajectory(np.zeros((2, 1)), np.zeros((1, 1))))

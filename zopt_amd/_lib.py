@@ -29,6 +29,9 @@ SYMBOLS = {
                                                 ctypes.c_int, ctypes.c_int]),
     "zm_ilqr_backward_f64": (ctypes.c_int, [_c_dp] * 11 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                            ctypes.c_void_p]),
+    # (model*, cost*, x0, l, L, xPrev, uPrev, alphas, n_alpha, active, xTraj, uTraj, J, alpha_idx, batch, T, stream)
+    "zm_rollout_linesearch_f64": (ctypes.c_int, [_c_dp] * 8 + [ctypes.c_int] + [_c_dp] * 5 +
+                                  [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
 }
 
 

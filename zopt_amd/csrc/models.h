@@ -1,0 +1,166 @@
+// Registered device models for the rollout / linearisation kernels (reference: arbitrary Python callables
+// differentiated by JAX; a HIP kernel needs the model in device code -- SURVEY section 7 "registered device models").
+//
+//   ZM_MODEL_LINEAR     x+ = A x + B u            (time-invariant A (n,n), B (n,m) shared by the batch; n <= 12, m <= 4)
+//                       -- the LQ problem of the reference's own iLQR test (tests/test_ilqrUtils.py:167-196)
+//   ZM_MODEL_QUADCOPTER x+ = x + dt * inertialDynamics(x, u)   (zopt/quadcopter.py:116-144 via :70-113, :23-67;
+//                       demos/iterativeLqr.py:35), n = 12, m = 4
+//   cost                c(x,u) = x^T Q x + u^T R u,  c_f(x) = x^T Qf x   (no 1/2: demos/iterativeLqr.py:12-13,37)
+//
+// The dynamics are templated on the scalar type so that the same code evaluated on dual numbers gives the
+// Jacobians (linearize kernel), as jax.jacobian does for the reference (pytrees.py:139-153).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/zopt_amd.h"
+
+namespace zm {
+
+constexpr int MAXN = 12;
+constexpr int MAXM = 4;
+
+// ---- forward-mode dual number (value + one directional derivative) --------------------------------------------
+struct Dual {
+    double v, d;
+};
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return {a.v + b.v, a.d + b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.d - b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a) { return {-a.v, -a.d}; }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.v * b.d + a.d * b.v}; }
+__device__ __forceinline__ Dual operator/(Dual a, Dual b) {
+    const double q = a.v / b.v;
+    return {q, (a.d - q * b.d) / b.v};
+}
+__device__ __forceinline__ Dual operator+(Dual a, double b) { return {a.v + b, a.d}; }
+__device__ __forceinline__ Dual operator+(double a, Dual b) { return {a + b.v, b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a, double b) { return {a.v - b, a.d}; }
+__device__ __forceinline__ Dual operator-(double a, Dual b) { return {a - b.v, -b.d}; }
+__device__ __forceinline__ Dual operator*(Dual a, double b) { return {a.v * b, a.d * b}; }
+__device__ __forceinline__ Dual operator*(double a, Dual b) { return {a * b.v, a * b.d}; }
+__device__ __forceinline__ Dual operator/(Dual a, double b) { return {a.v / b, a.d / b}; }
+__device__ __forceinline__ Dual operator/(double a, Dual b) {
+    const double q = a / b.v;
+    return {q, -q * b.d / b.v};
+}
+__device__ __forceinline__ Dual zsin(Dual a) { return {sin(a.v), cos(a.v) * a.d}; }
+__device__ __forceinline__ Dual zcos(Dual a) { return {cos(a.v), -sin(a.v) * a.d}; }
+__device__ __forceinline__ Dual ztan(Dual a) {
+    const double t = tan(a.v);
+    return {t, (1.0 + t * t) * a.d};
+}
+__device__ __forceinline__ double zsin(double a) { return sin(a); }
+__device__ __forceinline__ double zcos(double a) { return cos(a); }
+__device__ __forceinline__ double ztan(double a) { return tan(a); }
+
+// ---- quadcopter (zopt/quadcopter.py) ---------------------------------------------------------------------------
+// state [u,v,w,p,q,r,phi,theta,psi,x,y,z], control [thrust,mx,my,mz]; g = 9.807, mass = 2.5, I = eye(3) (:15-18).
+// Wind is zero (the iLQR / MPC demos roll out without wind: demos/iterativeLqr.py:35).
+template <typename S>
+__device__ __forceinline__ void quad_inertial_dynamics(const S (&x)[12], const S (&u)[4], S (&xd)[12]) {
+    constexpr double g = 9.807, mass = 2.5;
+    const S cphi = zcos(x[6]), sphi = zsin(x[6]);
+    const S cth = zcos(x[7]), sth = zsin(x[7]), tth = ztan(x[7]);
+    const S cpsi = zcos(x[8]), spsi = zsin(x[8]);
+    // _getAeroForceMomemnts (:51-67): force = lin * uvw + quad * uvw^2, moment = lin * pqr
+    const S fa0 = -0.2 * x[0] + -0.05 * (x[0] * x[0]);
+    const S fa1 = -0.2 * x[1] + -0.05 * (x[1] * x[1]);
+    const S fa2 = -0.3 * x[2] + -0.1 * (x[2] * x[2]);
+    const S ma0 = -0.1 * x[3], ma1 = -0.1 * x[4], ma2 = -0.05 * x[5];
+    // rigidBodyDynamics (:70-113)
+    const S d2x = -sth, d2y = sphi * cth, d2z = cphi * cth;                       // :94
+    const S ft0 = (fa0 + (mass * g) * d2x);                                       // force_control = m*[0,0,-thrust]
+    const S ft1 = (fa1 + (mass * g) * d2y);
+    const S ft2 = ((mass * (-u[0])) + fa2) + (mass * g) * d2z;                    // :98-100
+    // -cross(pqr, uvw) + force_total, times 1/m   (:106)
+    const S c0 = x[4] * x[2] - x[5] * x[1];
+    const S c1 = x[5] * x[0] - x[3] * x[2];
+    const S c2 = x[3] * x[1] - x[4] * x[0];
+    xd[0] = (1.0 / mass) * (ft0 - c0);
+    xd[1] = (1.0 / mass) * (ft1 - c1);
+    xd[2] = (1.0 / mass) * (ft2 - c2);
+    xd[3] = u[1] + ma0;                                                           // :107 (I = eye: cross(pqr,pqr) = 0)
+    xd[4] = u[2] + ma1;
+    xd[5] = u[3] + ma2;
+    // body rates -> Euler rates (:41-48, :108, :141)
+    xd[6] = (x[3] + (sphi * tth) * x[4]) + (cphi * tth) * x[5];
+    xd[7] = cphi * x[4] - sphi * x[5];
+    xd[8] = (sphi / cth) * x[4] + (cphi / cth) * x[5];
+    // xyzDot = R_b2i @ uvw, R_b2i as written in the reference (:31-37; [0][2] = cphi*sth*cpsi - sphi*spsi, quirk Q4)
+    xd[9] = ((cth * cpsi) * x[0] + (sphi * sth * cpsi - cphi * spsi) * x[1]) + (cphi * sth * cpsi - sphi * spsi) * x[2];
+    xd[10] = ((cth * spsi) * x[0] + (sphi * sth * spsi + cphi * cpsi) * x[1]) + (cphi * sth * spsi - sphi * cpsi) * x[2];
+    xd[11] = ((-sth) * x[0] + (sphi * cth) * x[1]) + (cphi * cth) * x[2];
+}
+
+// One discrete step x+ = f(x, u) of a registered model.  n, m are the model's dimensions (<= MAXN, MAXM).
+template <typename S>
+__device__ __forceinline__ void model_step(const zm_model_t& md, const S (&x)[MAXN], const S (&u)[MAXM], S (&xn)[MAXN]) {
+    if (md.kind == ZM_MODEL_QUADCOPTER) {
+        S xd[12];
+        quad_inertial_dynamics<S>(x, u, xd);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) xn[i] = x[i] + md.dt * xd[i];
+    } else {  // ZM_MODEL_LINEAR: A @ x + B @ u
+        const int n = md.n, m = md.m;
+#pragma unroll
+        for (int i = 0; i < MAXN; ++i) {
+            if (i < n) {
+                S ax = x[0] * md.A[i * n];
+#pragma unroll
+                for (int j = 1; j < MAXN; ++j)
+                    if (j < n) ax = ax + x[j] * md.A[i * n + j];
+                S bu = u[0] * md.B[i * m];
+#pragma unroll
+                for (int j = 1; j < MAXM; ++j)
+                    if (j < m) bu = bu + u[j] * md.B[i * m + j];
+                xn[i] = ax + bu;
+            } else {
+                xn[i] = x[i] * 0.0;
+            }
+        }
+    }
+}
+
+// c(x,u) = (x^T Q) x + (u^T R) u      (demos/iterativeLqr.py:12-13)
+__device__ __forceinline__ double running_cost(const zm_quadcost_t& cs, const int n, const int m, const double (&x)[MAXN],
+                                               const double (&u)[MAXM]) {
+    double cx = 0.0, cu = 0.0;
+#pragma unroll
+    for (int j = 0; j < MAXN; ++j) {
+        if (j < n) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < MAXN; ++i)
+                if (i < n) s = __builtin_fma(x[i], cs.Q[i * n + j], s);
+            cx = __builtin_fma(s, x[j], cx);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXM; ++j) {
+        if (j < m) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < MAXM; ++i)
+                if (i < m) s = __builtin_fma(u[i], cs.R[i * m + j], s);
+            cu = __builtin_fma(s, u[j], cu);
+        }
+    }
+    return cx + cu;
+}
+
+// c_f(x) = (x^T Qf) x
+__device__ __forceinline__ double terminal_cost(const zm_quadcost_t& cs, const int n, const double (&x)[MAXN]) {
+    double cx = 0.0;
+#pragma unroll
+    for (int j = 0; j < MAXN; ++j) {
+        if (j < n) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < MAXN; ++i)
+                if (i < n) s = __builtin_fma(x[i], cs.Qf[i * n + j], s);
+            cx = __builtin_fma(s, x[j], cx);
+        }
+    }
+    return cx;
+}
+
+}  // namespace zm

@@ -1,0 +1,171 @@
+// K6  rollout_linesearch -- batched policy rollout + parallel line search over step sizes, fp64, gfx950.
+//
+// Replaces zopt/ilqrUtils.py:33-66 (trajectoryRollout), :116-150 (forwardPass2), pytrees.py:215-220 (AffinePolicy call)
+// and pytrees.py:49-52 (CostFunction call) for registered device models (models.h).
+//
+// Mapping: ONE LANE per (trajectory, step size).  With 16 step sizes a wave64 carries 4 trajectories; the 16 lanes of a
+// trajectory read the same l_k, L_k, xPrev_k, uPrev_k addresses (one memory transaction each) and keep x, u in
+// registers.  Pass 1 accumulates J for every step size; a 16-lane argmin (NaN wins, first index on ties, as
+// jnp.argmin) picks the step; pass 2 re-rolls that step size (bit-identical arithmetic) and its first lane stores the
+// trajectory -- the other 15 rollouts never touch HBM.  This chain is latency/ALU-bound, not HBM-bound: it reads
+// 8(mn + 2m + n) = 544 B per trajectory step.
+#include "models.h"
+#include "zm_common.h"
+
+namespace zm {
+
+// one rollout; STORE: write xTraj/uTraj; returns J (0 when cost == nullptr)
+template <bool STORE>
+__device__ __forceinline__ double rollout_one(const zm_model_t& md, const zm_quadcost_t* cs, const double alpha,
+                                              const double* __restrict__ x0, const double* __restrict__ l,
+                                              const double* __restrict__ L, const double* __restrict__ xPrev,
+                                              const double* __restrict__ uPrev, double* __restrict__ xTraj,
+                                              double* __restrict__ uTraj, const int T) {
+    const int n = md.n, m = md.m;
+    double x[MAXN], u[MAXM], xn[MAXN];
+#pragma unroll
+    for (int i = 0; i < MAXN; ++i) x[i] = (i < n) ? x0[i] : 0.0;
+    if (STORE) {
+#pragma unroll
+        for (int i = 0; i < MAXN; ++i)
+            if (i < n) xTraj[i] = x[i];
+    }
+    double J = 0.0;
+    for (int k = 0; k < T; ++k) {
+        const double* Lk = L + (long)k * m * n;
+        const double* xp = xPrev + (long)k * n;
+        double dx[MAXN];
+#pragma unroll
+        for (int j = 0; j < MAXN; ++j) dx[j] = (j < n) ? (x[j] - xp[j]) : 0.0;
+#pragma unroll
+        for (int i = 0; i < MAXM; ++i) {
+            if (i < m) {
+                double s = 0.0;  // L_k @ dx
+#pragma unroll
+                for (int j = 0; j < MAXN; ++j)
+                    if (j < n) s = __builtin_fma(Lk[i * n + j], dx[j], s);
+                u[i] = (alpha * l[(long)k * m + i] + s) + uPrev[(long)k * m + i];   // pytrees.py:220, ilqrUtils.py:60
+            } else {
+                u[i] = 0.0;
+            }
+        }
+        if (cs) J += running_cost(*cs, n, m, x, u);
+        model_step<double>(md, x, u, xn);
+#pragma unroll
+        for (int i = 0; i < MAXN; ++i) x[i] = xn[i];
+        if (STORE) {
+#pragma unroll
+            for (int i = 0; i < MAXM; ++i)
+                if (i < m) uTraj[(long)k * m + i] = u[i];
+#pragma unroll
+            for (int i = 0; i < MAXN; ++i)
+                if (i < n) xTraj[(long)(k + 1) * n + i] = x[i];
+        }
+    }
+    if (cs) J += terminal_cost(*cs, n, x);
+    return J;
+}
+
+// NA = lanes per trajectory (power of two <= 16 that holds n_alpha)
+template <int NA>
+__global__ __launch_bounds__(64) void rollout_linesearch_kernel(const zm_model_t md, const zm_quadcost_t cost,
+                                                                const bool has_cost, const double* __restrict__ x0,
+                                                                const double* __restrict__ l, const double* __restrict__ L,
+                                                                const double* __restrict__ xPrev,
+                                                                const double* __restrict__ uPrev,
+                                                                const double* __restrict__ alphas, const int n_alpha,
+                                                                const int* __restrict__ active, double* __restrict__ xTraj,
+                                                                double* __restrict__ uTraj, double* __restrict__ Jout,
+                                                                int* __restrict__ idx_out, const long batch, const int T) {
+    constexpr int TPW = 64 / NA;  // trajectories per wave
+    const int lane = threadIdx.x;
+    const int a = lane % NA;
+    const long traj = (long)blockIdx.x * TPW + lane / NA;
+    const bool live = (traj < batch) && (a < n_alpha) && (active == nullptr || active[traj < batch ? traj : 0] != 0);
+    const long t = live ? traj : 0;
+    const int n = md.n, m = md.m;
+    const zm_quadcost_t* cs = has_cost ? &cost : nullptr;
+    const double alpha = alphas[a < n_alpha ? a : 0];
+    const double* x0t = x0 + t * n;
+    const double* lt = l + t * T * m;
+    const double* Lt = L + t * T * m * n;
+    const double* xpt = xPrev + t * (T + 1) * n;
+    const double* upt = uPrev + t * T * m;
+    double* xo = xTraj + t * (T + 1) * n;
+    double* uo = uTraj + t * T * m;
+
+    double J = 0.0;
+    int best = 0;
+    if (NA > 1) {
+        if (live) J = rollout_one<false>(md, cs, alpha, x0t, lt, Lt, xpt, upt, nullptr, nullptr, T);
+        // argmin over the NA lanes of this trajectory with jnp.argmin semantics: a NaN cost beats every number
+        // (also -inf), the first index wins among equals.  Dead lanes carry (+inf, index NA).
+        double key = live ? J : __builtin_inf();
+        int isn = (live && (J != J)) ? 1 : 0;
+        int who = live ? a : NA;
+#pragma unroll
+        for (int off = NA / 2; off >= 1; off >>= 1) {
+            const double ok = __shfl_xor(key, off);
+            const int on = __shfl_xor(isn, off);
+            const int ow = __shfl_xor(who, off);
+            const bool better = (on > isn) || (on == isn && ((on == 0 && ok < key) || ((on == 1 || ok == key) && ow < who)));
+            key = better ? ok : key;
+            isn = better ? on : isn;
+            who = better ? ow : who;
+        }
+        best = who < NA ? who : 0;
+    }
+    // every lane of the trajectory re-rolls the winning step size; lane 0 of the group stores
+    const double abest = alphas[best];
+    if (live) {
+        if (a == 0) {
+            const double Jb = rollout_one<true>(md, cs, abest, x0t, lt, Lt, xpt, upt, xo, uo, T);
+            if (Jout) Jout[t] = Jb;
+            if (idx_out) idx_out[t] = best;
+        }
+    }
+}
+
+}  // namespace zm
+
+extern "C" int zm_rollout_linesearch_f64(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0,
+                                         const double* l, const double* L, const double* xPrev, const double* uPrev,
+                                         const double* alphas, int n_alpha, const int32_t* active, double* xTraj,
+                                         double* uTraj, double* J, int32_t* alpha_idx, int64_t batch, int T,
+                                         void* stream) {
+    if (!model || !x0 || !l || !L || !xPrev || !uPrev || !alphas || !xTraj || !uTraj)
+        return zm::set_error(ZM_EINVAL, "zm_rollout_linesearch_f64: null pointer");
+    if (batch < 0 || T < 0 || n_alpha < 1 || n_alpha > 16)
+        return zm::set_error(ZM_EINVAL, "zm_rollout_linesearch_f64: bad size batch=%lld T=%d n_alpha=%d", (long long)batch,
+                             T, n_alpha);
+    if (n_alpha > 1 && !cost) return zm::set_error(ZM_EINVAL, "zm_rollout_linesearch_f64: a line search needs a cost");
+    zm_model_t md = *model;
+    if (md.kind == ZM_MODEL_QUADCOPTER) {
+        md.n = 12;
+        md.m = 4;
+    } else if (md.kind == ZM_MODEL_LINEAR) {
+        if (!md.A || !md.B) return zm::set_error(ZM_EINVAL, "zm_rollout_linesearch_f64: linear model needs A, B");
+    } else {
+        return zm::set_error(ZM_EUNSUPPORTED, "zm_rollout_linesearch_f64: unknown model kind %d", md.kind);
+    }
+    if (md.n < 1 || md.n > zm::MAXN || md.m < 1 || md.m > zm::MAXM)
+        return zm::set_error(ZM_EUNSUPPORTED, "zm_rollout_linesearch_f64: (n=%d, m=%d) not covered (n<=12, m<=4)", md.n, md.m);
+    if (cost && (!cost->Q || !cost->R || !cost->Qf))
+        return zm::set_error(ZM_EINVAL, "zm_rollout_linesearch_f64: cost needs Q, R, Qf");
+    if (batch == 0) return ZM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    zm_quadcost_t cs = cost ? *cost : zm_quadcost_t{nullptr, nullptr, nullptr};
+    const bool hc = cost != nullptr;
+    const int* act = (const int*)active;
+    if (n_alpha == 1) {
+        const unsigned blocks = (unsigned)((batch + 63) / 64);
+        hipLaunchKernelGGL((zm::rollout_linesearch_kernel<1>), dim3(blocks), dim3(64), 0, st, md, cs, hc, x0, l, L, xPrev,
+                           uPrev, alphas, n_alpha, act, xTraj, uTraj, J, (int*)alpha_idx, (long)batch, T);
+    } else {
+        const unsigned blocks = (unsigned)((batch + 3) / 4);
+        hipLaunchKernelGGL((zm::rollout_linesearch_kernel<16>), dim3(blocks), dim3(64), 0, st, md, cs, hc, x0, l, L, xPrev,
+                           uPrev, alphas, n_alpha, act, xTraj, uTraj, J, (int*)alpha_idx, (long)batch, T);
+    }
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}

@@ -11,7 +11,9 @@ import numpy as np
 
 from . import _arrays as arr
 from . import _lib
-from .pytrees import AffineDynamics, AffinePolicy, QuadraticCostFunction, QuadraticValueFunction  # noqa: F401
+from . import models as _models
+from .pytrees import (AffineDynamics, AffinePolicy, QuadraticCostFunction, QuadraticValueFunction,  # noqa: F401
+                      Trajectory)
 
 try:
     import torch
@@ -70,3 +72,61 @@ def backwardPass_ilqr(dynamics, cost, Vf):
     if fp32_in:
         dl, dL = dl.to(torch.float32), dL.to(torch.float32)
     return AffinePolicy(arr.result_like(dl, template), arr.result_like(dL, template))
+
+
+LINESEARCH_ALPHAS = 0.5 ** np.arange(16)   # reference ilqrUtils.py:145
+
+
+def _rollout(x0, dynFun, policy, trajPrev, alphas, costFun):
+    """Shared driver of trajectoryRollout / forwardPass2 on the rollout_linesearch kernel."""
+    if not hasattr(dynFun, "c_struct"):
+        raise TypeError("dynFun must be a registered device model (zopt_amd.models.LinearModel / QuadcopterEuler); "
+                        "arbitrary Python callables cannot run inside a HIP kernel")
+    if costFun is not None and not hasattr(costFun, "c_struct"):
+        raise TypeError("costFun must be a registered zopt_amd.models.QuadraticCost")
+    l, L = _fields(policy)
+    xPrev, uPrev = _fields(trajPrev)
+    n, m = dynFun.n, dynFun.m
+    shp = _shape(L)
+    lead, (N, mm, nn) = shp[:-3], shp[-3:]
+    if (mm, nn) != (m, n):
+        raise ValueError(f"policy.L has shape {shp}, model is (n={n}, m={m})")
+    for name, X, s in (("x0", x0, lead + (n,)), ("policy.l", l, lead + (N, m)), ("xPrev", xPrev, lead + (N + 1, n)),
+                       ("uPrev", uPrev, lead + (N, m))):
+        if _shape(X) != s:
+            raise ValueError(f"{name} has shape {_shape(X)}, expected {s}")
+    dt = torch.float64
+    dx0, dl, dL, dxp, dup = (arr.to_device(X, dt) for X in (x0, l, L, xPrev, uPrev))
+    dal = arr.to_device(np.asarray(alphas, dtype=np.float64), dt)
+    batch = 1
+    for d in lead:
+        batch *= int(d)
+    xT = torch.empty(lead + (N + 1, n), dtype=dt, device=dx0.device)
+    uT = torch.empty(lead + (N, m), dtype=dt, device=dx0.device)
+    J = torch.empty(lead, dtype=dt, device=dx0.device) if costFun is not None else None
+    md = dynFun.c_struct()
+    cs = costFun.c_struct() if costFun is not None else None
+    rc = _lib.lib().zm_rollout_linesearch_f64(
+        ctypes.addressof(md), ctypes.addressof(cs) if cs is not None else None, dx0.data_ptr(), dl.data_ptr(),
+        dL.data_ptr(), dxp.data_ptr(), dup.data_ptr(), dal.data_ptr(), int(dal.numel()), None, xT.data_ptr(),
+        uT.data_ptr(), J.data_ptr() if J is not None else None, None, batch, N, ctypes.c_void_p(arr.stream_ptr(dx0)))
+    _lib.check(rc, "rollout")
+    traj = Trajectory(arr.result_like(xT, L), arr.result_like(uT, L))
+    return traj, (arr.result_like(J, L) if J is not None else None)
+
+
+def trajectoryRollout(x0, dynFun, policy, trajPrev, alpha=1):
+    """Rollout a trajectory from the initial state using the provided control policy (reference ilqrUtils.py:33-66):
+    `u_k = alpha*l_k + L_k (x_k - xPrev_k) + uPrev_k`, `x_{k+1} = dynFun(x_k, u_k)`; returns Trajectory(xTraj (N+1,n)
+    incl. x0, uTraj (N,m)).  `dynFun` is a registered device model."""
+    traj, _ = _rollout(x0, dynFun, policy, trajPrev, [float(alpha)], None)
+    return traj
+
+
+def forwardPass2(x0, dynFun, costFun, policy, trajPrev):
+    """Simplified iLQR forward pass (reference ilqrUtils.py:116-150): roll out the 16 step sizes 0.5**j and return the
+    trajectory of minimum cost and that cost.  `costFun` is a registered QuadraticCost."""
+    traj, J = _rollout(x0, dynFun, policy, trajPrev, LINESEARCH_ALPHAS, costFun)
+    if not arr.is_torch(J) and np.ndim(J) == 0:
+        J = float(J)
+    return traj, J
