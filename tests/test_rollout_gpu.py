@@ -163,7 +163,7 @@ def test_nan_wins_argmin(mods):
                                  zo.Trajectory(prev.xTraj[0], prev.uTraj[0]))
     assert np.isnan(Js[0]) and (-np.inf in Js)           # the construction really has NaN competing with -inf
     assert np.isnan(rJ) and np.isnan(J[0])
-    assert np.array_equal(traj.uTraj[0], rt.uTraj)       # alpha = 1 (index 0)
+    assert np.array_equal(traj.uTraj[0], rt.uTraj, equal_nan=True)       # alpha = 1 (index 0)
 
 
 def test_unregistered_callable_is_rejected(mods):
