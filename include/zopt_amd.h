@@ -101,6 +101,50 @@ int zm_rollout_linesearch_f64(const zm_model_t* model, const zm_quadcost_t* cost
                               int n_alpha, const int32_t* active, double* xTraj, double* uTraj, double* J,
                               int32_t* alpha_idx, int64_t batch, int T, void* stream);
 
+/* First-order expansion of a registered model along a trajectory.
+ * Replaces: zopt/pytrees.py:139-153 AffineDynamics.from_function / from_trajectory (jax.jacobian of dynFun at
+ *           (xTraj[:-1], uTraj)):  f = dynFun(x_k,u_k), f_x = d dynFun/dx, f_u = d dynFun/du.
+ * in : xTraj (batch,T+1,n)  uTraj (batch,T,m)   active (batch) int32 or NULL (inactive trajectories are skipped)
+ * out: f (batch,T,n) or NULL   f_x (batch,T,n,n)   f_u (batch,T,n,m)
+ */
+int zm_linearize_dynamics_f64(const zm_model_t* model, const double* xTraj, const double* uTraj, const int32_t* active,
+                              double* f, double* f_x, double* f_u, int64_t batch, int T, void* stream);
+
+/* Second-order expansion of the registered quadratic cost along a trajectory, and of the terminal cost at x_T.
+ * Replaces: zopt/pytrees.py:100-115 QuadraticCostFunction.from_function / from_trajectory and :72-81
+ *           QuadraticValueFunction.fromTerminalCostFunction for c = x'Qx + u'Ru, c_f = x'Qf x:
+ *     c_x = (Q+Q')x  c_u = (R+R')u  c_xx = Q+Q'  c_ux = 0  c_uu = R+R'    v = x'Qf x  v_x = (Qf+Qf')x  v_xx = Qf+Qf'
+ * The Hessians do not depend on the trajectory: they are written ONCE (c_xx (n,n), c_ux (m,n), c_uu (m,m),
+ * v_xx (n,n)) and consumed with `shared_hessian = 1` by zm_ilqr_backward_ex_f64.
+ * in : xTraj (batch,T+1,n)  uTraj (batch,T,m)  active or NULL
+ * out: c (batch,T)  c_x (batch,T,n)  c_u (batch,T,m)  v (batch)  v_x (batch,n)   (each may be NULL)
+ *      c_xx (n,n)  c_ux (m,n)  c_uu (m,m)  v_xx (n,n)                              (each may be NULL)
+ */
+int zm_quadratize_cost_f64(const zm_quadcost_t* cost, int n, int m, const double* xTraj, const double* uTraj,
+                           const int32_t* active, double* c, double* c_x, double* c_u, double* v, double* v_x,
+                           double* c_xx, double* c_ux, double* c_uu, double* v_xx, int64_t batch, int T, void* stream);
+
+/* zm_ilqr_backward_f64 with (a) an `active` mask (inactive trajectories keep their previous l, L) and
+ * (b) `shared_hessian` != 0: c_xx (n,n), c_ux (m,n), c_uu (m,m) and vf_xx (n,n) are single matrices shared by every
+ * trajectory and step (time-invariant quadratic cost) instead of (batch,T,.,.) / (batch,.,.) arrays. */
+int zm_ilqr_backward_ex_f64(const double* f_x, const double* f_u, const double* c_x, const double* c_u,
+                            const double* c_xx, const double* c_ux, const double* c_uu, const double* vf_x,
+                            const double* vf_xx, const int32_t* active, int shared_hessian, double* l, double* L,
+                            int64_t batch, int T, int n, int m, void* stream);
+
+/* Batched projection onto the positive definite cone: A <- V max(w, eps) V^T with (w, V) = eigh((A + A^T)/2).
+ * Replaces: zopt/ilqrUtils.py:217-219 ensurePositiveDefinite (jnp.linalg.eigh symmetrises its input) and its users
+ *           :254-257 conditionValueFunction (k = n).       in/out: A (count,k,k) in place, k <= 16.
+ */
+int zm_psd_project_f64(double* A, int64_t count, int k, double eps, void* stream);
+
+/* Same projection applied to the stacked cost Hessian [[c_xx, c_ux^T],[c_ux, c_uu]] of every step, written back
+ * into its blocks.  Replaces: zopt/ilqrUtils.py:222-234 conditionQuadraticCost.
+ * in/out: c_xx (count,n,n)  c_ux (count,m,n)  c_uu (count,m,m) in place (count = batch*T, or 1 for a shared Hessian)
+ */
+int zm_condition_cost_f64(double* c_xx, double* c_ux, double* c_uu, int64_t count, int n, int m, double eps,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -365,8 +365,8 @@ def quad_bodyRatesToEulerRatesRotationMatrix(phi, theta):
 
 def quad_rigidBodyDynamics(state, control, wind_body=np.zeros(3)):
     """quadcopter.py:70-113: state [u,v,w,p,q,r,phi,theta(,...)] -> 8 derivatives (quirk Q5: reads only [0:8])."""
-    state = np.asarray(state, dtype=np.float64)
-    control = np.asarray(control, dtype=np.float64)
+    state = np.asarray(state)      # (complex allowed: the oracle differentiates by the complex-step method)
+    control = np.asarray(control)
     uvw, pqr = state[0:3], state[3:6]
     phi, theta = state[6:8]
     thrust, mxyz = control[0], control[1:4]
@@ -385,7 +385,7 @@ def quad_rigidBodyDynamics(state, control, wind_body=np.zeros(3)):
 
 def quad_inertialDynamics(state, control, wind_ned=np.zeros(3)):
     """quadcopter.py:116-144: 12-state xDot = f(x, u); state [u,v,w,p,q,r,phi,theta,psi,x,y,z]."""
-    state = np.asarray(state, dtype=np.float64)
+    state = np.asarray(state)
     uvw, pqr = state[0:3], state[3:6]
     phi, theta, psi = state[6:9]
     R_b2i = quad_bodyToInertialRotationMatrix(phi, theta, psi)
@@ -406,3 +406,82 @@ def quadratic_costs(Q, R, Qf):
     """runningCost = x'Qx + u'Ru, terminalCost = x'Qf x (demos/iterativeLqr.py:12-13,37; no 1/2, quirk Q7)."""
     Q, R, Qf = (np.asarray(t, dtype=np.float64) for t in (Q, R, Qf))
     return (lambda x, u: x @ Q @ x + u @ R @ u), (lambda x: x @ Qf @ x)
+
+
+# ----------------------------------------------------------------------------------------
+# A9  linearisers                      reference pytrees.py:72-81, 100-115, 139-153
+# ----------------------------------------------------------------------------------------
+def jacobians(dynFun, x, u, h=1e-30):
+    """f, d f/dx, d f/du at (x, u) by the complex-step method (exact to rounding for analytic dynFun) -- the role
+    jax.jacobian plays in AffineDynamics.from_function (pytrees.py:139-145)."""
+    x = np.asarray(x, dtype=np.float64)
+    u = np.asarray(u, dtype=np.float64)
+    n, m = x.shape[0], u.shape[0]
+    f = np.real(dynFun(x, u))
+    f_x = np.empty((n, n))
+    f_u = np.empty((n, m))
+    for j in range(n):
+        xp = x.astype(np.complex128)
+        xp[j] += 1j * h
+        f_x[:, j] = np.imag(dynFun(xp, u.astype(np.complex128))) / h
+    for j in range(m):
+        up = u.astype(np.complex128)
+        up[j] += 1j * h
+        f_u[:, j] = np.imag(dynFun(x.astype(np.complex128), up)) / h
+    return f, f_x, f_u
+
+
+def affine_dynamics_from_trajectory(dynFun, traj: Trajectory) -> AffineDynamics:
+    """AffineDynamics.from_trajectory (pytrees.py:147-153): expansion at (xTraj[:-1], uTraj)."""
+    xTraj, uTraj = traj
+    out = [jacobians(dynFun, xTraj[k], uTraj[k]) for k in range(uTraj.shape[0])]
+    return AffineDynamics(np.stack([o[0] for o in out]), np.stack([o[1] for o in out]), np.stack([o[2] for o in out]))
+
+
+def quadratic_cost_from_trajectory(Q, R, traj: Trajectory) -> QuadraticCostFunction:
+    """QuadraticCostFunction.from_trajectory (pytrees.py:109-115) for c = x'Qx + u'Ru: the values autodiff returns,
+    c_x = (Q+Q')x, c_u = (R+R')u, c_xx = Q+Q', c_ux = 0 (m,n), c_uu = R+R'."""
+    xTraj, uTraj = traj
+    N = uTraj.shape[0]
+    n, m = xTraj.shape[1], uTraj.shape[1]
+    x = xTraj[:-1]
+    c = np.einsum('ki,ij,kj->k', x, Q, x) + np.einsum('ki,ij,kj->k', uTraj, R, uTraj)
+    return QuadraticCostFunction(c, x @ (Q + Q.T).T, uTraj @ (R + R.T).T, np.tile(Q + Q.T, (N, 1, 1)),
+                                 np.zeros((N, m, n)), np.tile(R + R.T, (N, 1, 1)))
+
+
+def terminal_value_function(Qf, xf) -> QuadraticValueFunction:
+    """QuadraticValueFunction.fromTerminalCostFunction (pytrees.py:72-81) for c_f = x'Qf x."""
+    return QuadraticValueFunction(xf @ Qf @ xf, (Qf + Qf.T) @ xf, Qf + Qf.T)
+
+
+# ----------------------------------------------------------------------------------------
+# A8  iterativeLqr                                         reference ilqrUtils.py:260-327
+# ----------------------------------------------------------------------------------------
+def iterativeLqr(dynFun, Q, R, Qf, x0, uGuess, maxIter=100, tol=1e-3, return_iters=False):
+    """iLQR loop of ilqrUtils.py:290-327 for an analytic `dynFun` and the quadratic cost (Q, R, Qf).
+    Returns (Trajectory, L (N,m,n), J, converged)."""
+    Q, R, Qf = (np.asarray(t, dtype=np.float64) for t in (Q, R, Qf))
+    x0 = np.asarray(x0, dtype=np.float64)
+    uGuess = np.asarray(uGuess, dtype=np.float64)
+    n = x0.shape[0]
+    N, m = uGuess.shape
+    runningCost, terminalCost = quadratic_costs(Q, R, Qf)
+    policy = AffinePolicy(uGuess, np.zeros((N, m, n)))                                   # :293
+    traj_prev = Trajectory(np.zeros((N + 1, n)), np.zeros((N, m)))                        # :294
+    traj = trajectoryRollout(x0, dynFun, policy, traj_prev)                               # :297
+    J = trajectoryCost(runningCost, terminalCost, traj)                                   # :298
+    converged, it = False, 0
+    while (not converged) and it < maxIter:                                               # :301-303
+        dyn = affine_dynamics_from_trajectory(dynFun, traj)                               # :308
+        cost = quadratic_cost_from_trajectory(Q, R, traj)                                 # :309
+        Vf = terminal_value_function(Qf, traj.xTraj[-1])                                  # :310
+        cost = conditionQuadraticCost(cost)                                               # :312
+        Vf = conditionValueFunction(Vf)                                                   # :313
+        policy = backwardPass_ilqr(dyn, cost, Vf)                                         # :315
+        traj_new, J_new = forwardPass2(x0, dynFun, runningCost, terminalCost, policy, traj)   # :316
+        converged = bool(abs(J - J_new) <= tol)                                           # :318
+        traj, J = traj_new, J_new
+        it += 1
+    out = (traj, policy.L, J, converged)
+    return out + (it,) if return_iters else out

@@ -1,0 +1,190 @@
+"""GPU tests for K5 psd_project, K7 linearize/quadratize and the A8 iterativeLqr driver (reference ilqrUtils.py:217-327,
+pytrees.py:72-153)."""
+import numpy as np
+import pytest
+
+from oracle import zopt_oracle as zo
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import torch
+    assert torch.cuda.is_available()
+    from zopt_amd import _lib, ilqrUtils, models, pytrees
+    return ilqrUtils, models, pytrees, _lib
+
+
+# ---------------------------------------------------------------- K5
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 8, 12, 15, 16])
+def test_ensurePositiveDefinite_parity(mods, k):
+    ilqr = mods[0]
+    rng = np.random.default_rng(k)
+    M = rng.standard_normal((7, k, k))
+    A = M + np.swapaxes(M, -1, -2)                      # symmetric indefinite: the clamp is active
+    A[0] = M[0]                                          # nonsymmetric input: eigh symmetrises it
+    A[1] = M[1] @ M[1].T + np.eye(k)                     # already PD: (numerically) unchanged
+    A[2] = np.diag(np.linspace(-1.0, 2.0, k))            # diagonal
+    out = ilqr.ensurePositiveDefinite(A)
+    ref = zo.ensurePositiveDefinite(A)
+    assert out.shape == A.shape
+    assert np.max(np.abs(out - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
+    w = np.linalg.eigvalsh(0.5 * (out + np.swapaxes(out, -1, -2)))
+    assert np.min(w) >= 1e-3 * (1 - 1e-9)
+    assert out[1] == pytest.approx(A[1], rel=1e-12, abs=1e-13)
+
+
+def test_conditionQuadraticCost_parity(mods):
+    ilqr, _, pt, _ = mods
+    rng = np.random.default_rng(1)
+    b, N, n, m = 3, 5, 12, 4
+    M = rng.standard_normal((b, N, n + m, n + m))
+    H = M + np.swapaxes(M, -1, -2)
+    cost = (rng.standard_normal((b, N)), rng.standard_normal((b, N, n)), rng.standard_normal((b, N, m)),
+            np.ascontiguousarray(H[..., :n, :n]), np.ascontiguousarray(H[..., n:, :n]), np.ascontiguousarray(H[..., n:, n:]))
+    out = ilqr.conditionQuadraticCost(pt.QuadraticCostFunction(*cost))
+    ref = zo.conditionQuadraticCost(zo.QuadraticCostFunction(*cost))
+    for name in ("c_xx", "c_ux", "c_uu"):
+        assert _rel(getattr(out, name), getattr(ref, name)) <= 1e-12
+    assert out.c is cost[0] and out.c_x is cost[1]
+    Vf = ilqr.conditionValueFunction(pt.QuadraticValueFunction(0.0, np.zeros(n), H[0, 0, :n, :n]))
+    assert _rel(Vf.v_xx, zo.ensurePositiveDefinite(H[0, 0, :n, :n])) <= 1e-12
+
+
+# ---------------------------------------------------------------- K7
+def _lin_call(mods, model, xT, uT):
+    import ctypes
+    import torch
+    _, _, _, _lib = mods
+    b, Np1, n = xT.shape
+    N, m = Np1 - 1, uT.shape[-1]
+    dx, du = torch.as_tensor(xT, device="cuda"), torch.as_tensor(uT, device="cuda")
+    f = torch.empty((b, N, n), dtype=torch.float64, device="cuda")
+    f_x = torch.empty((b, N, n, n), dtype=torch.float64, device="cuda")
+    f_u = torch.empty((b, N, n, m), dtype=torch.float64, device="cuda")
+    md = model.c_struct()
+    rc = _lib.lib().zm_linearize_dynamics_f64(ctypes.addressof(md), dx.data_ptr(), du.data_ptr(), None, f.data_ptr(),
+                                              f_x.data_ptr(), f_u.data_ptr(), b, N, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    return f.cpu().numpy(), f_x.cpu().numpy(), f_u.cpu().numpy()
+
+
+def test_linearize_quadcopter_matches_complex_step(mods):
+    """Forward-mode dual numbers on the device model vs the oracle's complex-step Jacobians (pytrees.py:139-153)."""
+    models = mods[1]
+    rng = np.random.default_rng(5)
+    b, N = 3, 7
+    xT = 0.4 * rng.standard_normal((b, N + 1, 12))
+    uT = np.array([9.807, 0, 0, 0]) + 0.5 * rng.standard_normal((b, N, 4))
+    f, f_x, f_u = _lin_call(mods, models.QuadcopterEuler(0.1), xT, uT)
+    step = zo.quad_euler_step(0.1)
+    for i in range(b):
+        ref = zo.affine_dynamics_from_trajectory(step, zo.Trajectory(xT[i], uT[i]))
+        assert _rel(f[i], ref.f) <= 1e-13 and _rel(f_x[i], ref.f_x) <= 1e-12 and _rel(f_u[i], ref.f_u) <= 1e-12
+
+
+def test_linearize_linear_model_is_exact(mods):
+    models = mods[1]
+    rng = np.random.default_rng(6)
+    A, B = rng.standard_normal((5, 5)), rng.standard_normal((5, 2))
+    xT, uT = rng.standard_normal((2, 4, 5)), rng.standard_normal((2, 3, 2))
+    f, f_x, f_u = _lin_call(mods, models.LinearModel(A, B), xT, uT)
+    assert np.array_equal(f_x, np.broadcast_to(A, f_x.shape)) and np.array_equal(f_u, np.broadcast_to(B, f_u.shape))
+    assert f == pytest.approx(np.einsum('ij,bkj->bki', A, xT[:, :-1]) + np.einsum('ij,bkj->bki', B, uT), rel=1e-14)
+
+
+def test_quadratize_cost_parity(mods):
+    import ctypes
+    import torch
+    _, models, _, _lib = mods
+    rng = np.random.default_rng(8)
+    b, N, n, m = 4, 6, 12, 4
+    Q, R, Qf = rng.standard_normal((n, n)), rng.standard_normal((m, m)), rng.standard_normal((n, n))   # nonsymmetric on purpose
+    cost = models.QuadraticCost(Q, R, Qf)
+    xT, uT = rng.standard_normal((b, N + 1, n)), rng.standard_normal((b, N, m))
+    t = lambda *s: torch.empty(s, dtype=torch.float64, device="cuda")
+    c, c_x, c_u, v, v_x = t(b, N), t(b, N, n), t(b, N, m), t(b), t(b, n)
+    c_xx, c_ux, c_uu, v_xx = t(n, n), t(m, n), t(m, m), t(n, n)
+    cs = cost.c_struct()
+    dx, du = torch.as_tensor(xT, device="cuda"), torch.as_tensor(uT, device="cuda")
+    rc = _lib.lib().zm_quadratize_cost_f64(ctypes.addressof(cs), n, m, dx.data_ptr(), du.data_ptr(), None, c.data_ptr(),
+                                           c_x.data_ptr(), c_u.data_ptr(), v.data_ptr(), v_x.data_ptr(), c_xx.data_ptr(),
+                                           c_ux.data_ptr(), c_uu.data_ptr(), v_xx.data_ptr(), b, N, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    for i in range(b):
+        ref = zo.quadratic_cost_from_trajectory(Q, R, zo.Trajectory(xT[i], uT[i]))
+        vf = zo.terminal_value_function(Qf, xT[i, -1])
+        assert _rel(c[i].cpu().numpy(), ref.c) <= 1e-13 and _rel(c_x[i].cpu().numpy(), ref.c_x) <= 1e-13
+        assert _rel(c_u[i].cpu().numpy(), ref.c_u) <= 1e-13
+        assert abs(v[i].item() - vf.v) <= 1e-13 * abs(vf.v) and _rel(v_x[i].cpu().numpy(), vf.v_x) <= 1e-13
+    assert np.array_equal(c_xx.cpu().numpy(), Q + Q.T) and np.array_equal(c_uu.cpu().numpy(), R + R.T)
+    assert np.array_equal(v_xx.cpu().numpy(), Qf + Qf.T) and not c_ux.cpu().numpy().any()
+
+
+# ---------------------------------------------------------------- A8
+def test_kat_iterativeLqr(mods):
+    """reference tests/test_ilqrUtils.py:167-181: A=B=Q=R=I, N=3, x0=(2,1), uGuess=0 -> converged.  The problem is LQ, so
+    the result must also be the Riccati-optimal trajectory."""
+    ilqr, models, pt, _ = mods
+    I = np.eye(2)
+    cost = models.QuadraticCost(I, I, I)
+    x0 = np.array([2.0, 1.0])
+    traj, L, J, converged = ilqr.iterativeLqr(models.LinearModel(I, I), cost.runningCost, cost.terminalCost, x0,
+                                              np.zeros((3, 2)))
+    assert converged is True
+    rt, rL, rJ, rc = zo.iterativeLqr(lambda x, u: x + u, I, I, I, x0, np.zeros((3, 2)))
+    assert rc
+    assert _rel(traj.xTraj, rt.xTraj) <= 1e-9 and _rel(traj.uTraj, rt.uTraj) <= 1e-9 and _rel(L, rL) <= 1e-9
+    assert J == pytest.approx(rJ, rel=1e-10)
+    assert isinstance(traj, pt.Trajectory) and traj.xTraj.shape == (4, 2) and L.shape == (3, 2, 2)
+
+
+def test_iterativeLqr_quadcopter_demo_problem(mods):
+    """demos/iterativeLqr.py:22-39: quadcopter, dt=0.1, N=100, Q=I12, R=I4, terminal 10 x'Qx, x0[9:12]=(10,10,10),
+    uGuess=uTrim -- plus perturbed starts, against the CPU oracle loop (same iteration-by-iteration decisions)."""
+    ilqr, models, pt, _ = mods
+    N = 100
+    Q, R = np.eye(12), np.eye(4)
+    Qf = 10 * Q
+    cost = models.QuadraticCost(Q, R, Qf)
+    model = models.QuadcopterEuler(0.1)
+    rng = np.random.default_rng(2)
+    x0 = np.zeros((3, 12))
+    x0[0, 9:12] = [10, 10, 10]
+    x0[1:, 9:12] = rng.uniform(-10, 10, (2, 3))
+    uGuess = np.tile(models.QuadcopterEuler.uTrim, (3, N, 1))
+    traj, L, J, converged = ilqr.iterativeLqr(model, cost, cost, x0, uGuess)
+    assert traj.xTraj.shape == (3, N + 1, 12) and L.shape == (3, N, 4, 12) and J.shape == (3,) and converged.dtype == bool
+    step = zo.quad_euler_step(0.1)
+    for i in range(3):
+        rt, rL, rJ, rc = zo.iterativeLqr(step, Q, R, Qf, x0[i], uGuess[i])
+        assert bool(converged[i]) == rc
+        assert J[i] == pytest.approx(rJ, rel=1e-7)
+        assert _rel(traj.xTraj[i], rt.xTraj) <= 1e-6 and _rel(traj.uTraj[i], rt.uTraj) <= 1e-6
+        assert _rel(L[i], rL) <= 1e-6
+    assert np.all(converged)
+
+
+def test_iterativeLqr_maxiter_and_batch_independence(mods):
+    ilqr, models, _, _ = mods
+    N = 30
+    cost = models.QuadraticCost(np.eye(12), 0.5 * np.eye(4), 10 * np.eye(12))
+    model = models.QuadcopterEuler(0.1)
+    rng = np.random.default_rng(3)
+    x0 = np.zeros((6, 12))
+    x0[:, 9:12] = rng.uniform(-5, 5, (6, 3))
+    ug = np.tile(models.QuadcopterEuler.uTrim, (6, N, 1))
+    t1, L1, J1, c1 = ilqr.iterativeLqr(model, cost, cost, x0, ug, maxIter=1)
+    assert not c1.any()                                   # one iteration can never report convergence from the guess
+    tf, Lf, Jf, cf = ilqr.iterativeLqr(model, cost, cost, x0, ug)
+    assert np.all(Jf <= J1 + 1e-9) and cf.all()
+    # solving a sub-batch alone gives the same answers: trajectories are independent
+    ts, Ls, Js, cs = ilqr.iterativeLqr(model, cost, cost, x0[2:4], ug[2:4])
+    assert np.array_equal(ts.xTraj, tf.xTraj[2:4]) and np.array_equal(Ls, Lf[2:4]) and np.array_equal(Js, Jf[2:4])

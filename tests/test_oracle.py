@@ -188,3 +188,38 @@ def test_kat_quadcopter_model():
     # quirk Q4 is reproduced: entry [0][2] of the body-to-inertial matrix for a general attitude
     R = zo.quad_bodyToInertialRotationMatrix(0.3, 0.2, 0.1)
     assert R[0, 2] == pytest.approx(np.cos(0.3) * np.sin(0.2) * np.cos(0.1) - np.sin(0.3) * np.sin(0.1))
+
+
+def test_complex_step_jacobians_match_finite_differences():
+    """The oracle's lineariser (complex step) against central differences on the quadcopter Euler map."""
+    rng = np.random.default_rng(3)
+    step = zo.quad_euler_step(0.1)
+    x = 0.3 * rng.standard_normal(12)
+    u = np.array([9.807, 0, 0, 0]) + 0.3 * rng.standard_normal(4)
+    f, f_x, f_u = zo.jacobians(step, x, u)
+    assert f == pytest.approx(step(x, u), rel=1e-15)
+    h = 1e-6
+    for j in range(12):
+        e = np.zeros(12); e[j] = h
+        assert f_x[:, j] == pytest.approx((step(x + e, u) - step(x - e, u)) / (2 * h), abs=1e-8)
+    for j in range(4):
+        e = np.zeros(4); e[j] = h
+        assert f_u[:, j] == pytest.approx((step(x, u + e) - step(x, u - e)) / (2 * h), abs=1e-8)
+
+
+def test_kat_iterativeLqr_converges_to_riccati():
+    """reference tests/test_ilqrUtils.py:167-181 (A=B=Q=R=I, N=3, x0=(2,1)) asserts `converged`; the problem is LQ, so
+    the iLQR trajectory must in addition be the Riccati-optimal one (hand check via the LQR gains)."""
+    I = np.eye(2)
+    f = lambda x, u: I @ x + I @ u
+    x0 = np.array([2.0, 1.0])
+    traj, L, J, converged, iters = zo.iterativeLqr(f, I, I, I, x0, np.zeros((3, 2)), return_iters=True)
+    assert converged and iters <= 3
+    K = zo.discreteFiniteHorizonLqr(_tile(I2, 4), _tile(I2, 4), _tile(I2, 4), _tile(I2, 4), 4)[1:]   # stage gains with terminal Q
+    x = x0.copy()
+    for k in range(3):
+        u = -K[k] @ x
+        assert traj.uTraj[k] == pytest.approx(u, abs=1e-9)
+        x = x + u
+    assert traj.xTraj[-1] == pytest.approx(x, abs=1e-9)
+    assert L == pytest.approx(-K, abs=1e-9)

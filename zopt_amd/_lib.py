@@ -32,6 +32,17 @@ SYMBOLS = {
     # (model*, cost*, x0, l, L, xPrev, uPrev, alphas, n_alpha, active, xTraj, uTraj, J, alpha_idx, batch, T, stream)
     "zm_rollout_linesearch_f64": (ctypes.c_int, [_c_dp] * 8 + [ctypes.c_int] + [_c_dp] * 5 +
                                   [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    # (model*, xTraj, uTraj, active, f, f_x, f_u, batch, T, stream)
+    "zm_linearize_dynamics_f64": (ctypes.c_int, [_c_dp] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    # (cost*, n, m, xTraj, uTraj, active, c, c_x, c_u, v, v_x, c_xx, c_ux, c_uu, v_xx, batch, T, stream)
+    "zm_quadratize_cost_f64": (ctypes.c_int, [_c_dp, ctypes.c_int, ctypes.c_int] + [_c_dp] * 12 +
+                               [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    # (f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, active, shared_hessian, l, L, batch, T, n, m, stream)
+    "zm_ilqr_backward_ex_f64": (ctypes.c_int, [_c_dp] * 10 + [ctypes.c_int] + [_c_dp] * 2 +
+                                [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "zm_psd_project_f64": (ctypes.c_int, [_c_dp, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
+    "zm_condition_cost_f64": (ctypes.c_int, [_c_dp] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                                          ctypes.c_void_p]),
 }
 
 

@@ -38,8 +38,7 @@ struct IlqrAddr {
     const double* pCu;
     const double* pcv;
     double* pOut;        // L_k[g][c] (c < n) or l_k[g] (c == NP)
-    int dF, dC, sF, sCu, scv, sOut;
-    int nn;
+    int dF, dC, sF, sC, sCu, scv, sOut;
     bool rowok[KS], vF[KS], vC[KS], vCu, vcv, vOut, vL, cA;
     double cu_pad;
 };
@@ -52,7 +51,7 @@ __device__ __forceinline__ void ilqr_load_step(IlqrStepRegs<KS>& d, IlqrAddr<KS>
     a.pF0 -= a.sF;
 #pragma unroll
     for (int s = 0; s < KS; ++s) cc[s] = a.pC0[a.rowok[s] ? s * a.dC : 0];
-    a.pC0 -= a.nn;
+    a.pC0 -= a.sC;
     const double cu = *a.pCu;
     a.pCu -= a.sCu;
     const double cv = *a.pcv;
@@ -147,16 +146,17 @@ __global__ __launch_bounds__(64) void ilqr_backward_t16_f64(
     const double* __restrict__ f_x, const double* __restrict__ f_u, const double* __restrict__ c_x,
     const double* __restrict__ c_u, const double* __restrict__ c_xx, const double* __restrict__ c_ux,
     const double* __restrict__ c_uu, const double* __restrict__ vf_x, const double* __restrict__ vf_xx,
-    double* __restrict__ lout, double* __restrict__ Lout, const int T, const int n, const int m) {
+    const int* __restrict__ active, const int shared_h, double* __restrict__ lout, double* __restrict__ Lout,
+    const int T, const int n, const int m) {
     constexpr int NP = 4 * KS;
     const int lane = threadIdx.x;
     const long traj = blockIdx.x;
+    if (active && active[traj] == 0) return;  // whole wave leaves: this trajectory keeps its previous policy
     const int g = lane >> 4, c = lane & 15;
     __shared__ double sm[ILQR_LDS_DOUBLES];
 
     IlqrAddr<KS> a;
     const int nn = n * n, nm = n * m, mm = m * m;
-    a.nn = nn;
     const bool cA = c < n;
     a.cA = cA;
     const bool cB = (c >= NP) && (c < NP + m);
@@ -165,9 +165,11 @@ __global__ __launch_bounds__(64) void ilqr_backward_t16_f64(
     const double* fut = f_u + last * nm;
     const double* cxt = c_x + last * n;
     const double* cut = c_u + last * m;
-    const double* cxxt = c_xx + last * nn;
-    const double* cuxt = c_ux + last * nm;
-    const double* cuut = c_uu + last * mm;
+    // shared_h: one time-invariant cost Hessian for every trajectory and step (strides 0)
+    const double* cxxt = shared_h ? c_xx : c_xx + last * nn;
+    const double* cuxt = shared_h ? c_ux : c_ux + last * nm;
+    const double* cuut = shared_h ? c_uu : c_uu + last * mm;
+    a.sC = shared_h ? 0 : nn;
     const bool row0 = g < n;
     const bool laneA = row0 && cA, laneB = row0 && cB;
     a.dF = laneA ? 4 * n : laneB ? 4 * m : 0;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(64) void ilqr_backward_t16_f64(
     const bool vux = (g < m) && cA, vuu = (g < m) && cB;
     a.vCu = vux || vuu;
     a.pCu = vux ? (cuxt + g * n + c) : vuu ? (cuut + g * m + (c - NP)) : cuxt;
-    a.sCu = vuu ? mm : nm;
+    a.sCu = shared_h ? 0 : (vuu ? mm : nm);
     a.cu_pad = (g >= m && c == NP + g) ? 1.0 : 0.0;
     a.vcv = cA || cB;
     a.pcv = cA ? (cxt + c) : cB ? (cut + (c - NP)) : cxt;
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(64) void ilqr_backward_t16_f64(
     // terminal value function
     double Vxx[KS], vxr[KS];
     {
-        const double* vxx = vf_xx + traj * nn;
+        const double* vxx = shared_h ? vf_xx : vf_xx + traj * nn;
         const double* vx = vf_x + traj * n;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -246,10 +248,10 @@ __global__ __launch_bounds__(64) void ilqr_backward_t16_f64(
 
 }  // namespace zm
 
-extern "C" int zm_ilqr_backward_f64(const double* f_x, const double* f_u, const double* c_x, const double* c_u,
-                                    const double* c_xx, const double* c_ux, const double* c_uu, const double* vf_x,
-                                    const double* vf_xx, double* l, double* L, int64_t batch, int T, int n, int m,
-                                    void* stream) {
+extern "C" int zm_ilqr_backward_ex_f64(const double* f_x, const double* f_u, const double* c_x, const double* c_u,
+                                       const double* c_xx, const double* c_ux, const double* c_uu, const double* vf_x,
+                                       const double* vf_xx, const int32_t* active, int shared_hessian, double* l,
+                                       double* L, int64_t batch, int T, int n, int m, void* stream) {
     if (!f_x || !f_u || !c_x || !c_u || !c_xx || !c_ux || !c_uu || !vf_x || !vf_xx || !l || !L)
         return zm::set_error(ZM_EINVAL, "zm_ilqr_backward_f64: null pointer");
     if (batch < 0 || T < 1 || n < 1 || m < 1)
@@ -262,15 +264,25 @@ extern "C" int zm_ilqr_backward_f64(const double* f_x, const double* f_u, const 
     if (batch == 0) return ZM_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)batch), block(64);
+    const int* act = (const int*)active;
+    const int sh = shared_hessian ? 1 : 0;
     if (n <= 4)
         hipLaunchKernelGGL((zm::ilqr_backward_t16_f64<1>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
-                           vf_xx, l, L, T, n, m);
+                           vf_xx, act, sh, l, L, T, n, m);
     else if (n <= 8)
         hipLaunchKernelGGL((zm::ilqr_backward_t16_f64<2>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
-                           vf_xx, l, L, T, n, m);
+                           vf_xx, act, sh, l, L, T, n, m);
     else
         hipLaunchKernelGGL((zm::ilqr_backward_t16_f64<3>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
-                           vf_xx, l, L, T, n, m);
+                           vf_xx, act, sh, l, L, T, n, m);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
+}
+
+extern "C" int zm_ilqr_backward_f64(const double* f_x, const double* f_u, const double* c_x, const double* c_u,
+                                    const double* c_xx, const double* c_ux, const double* c_uu, const double* vf_x,
+                                    const double* vf_xx, double* l, double* L, int64_t batch, int T, int n, int m,
+                                    void* stream) {
+    return zm_ilqr_backward_ex_f64(f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, 0, l, L, batch, T, n, m,
+                                   stream);
 }

@@ -1,0 +1,182 @@
+// K7  linearize_dynamics / quadratize_cost -- model expansions along a trajectory, fp64, gfx950.
+//
+// Replaces the JAX autodiff constructors of zopt/pytrees.py: AffineDynamics.from_trajectory (:139-153),
+// QuadraticCostFunction.from_trajectory (:100-115) and QuadraticValueFunction.fromTerminalCostFunction (:72-81)
+// for registered device models (models.h).
+//
+// linearize_dynamics: embarrassingly parallel over (trajectory, step): 16 lanes per point, lane j evaluates the model
+// once on forward-mode dual numbers seeded in direction e_j of z = [x ; u] and owns COLUMN j of [f_x | f_u]
+// (exactly what jax.jacobian builds column by column).  4 points per wave64.
+// quadratize_cost: c_x = (Q+Q^T)x, c_u = (R+R^T)u, c = x^TQx + u^TRu per point; the Hessians Q+Q^T, R+R^T, Qf+Qf^T
+// are trajectory-independent and written once.
+#include "models.h"
+#include "zm_common.h"
+
+namespace zm {
+
+__global__ __launch_bounds__(64) void linearize_dynamics_kernel(const zm_model_t md, const double* __restrict__ xTraj,
+                                                                const double* __restrict__ uTraj,
+                                                                const int* __restrict__ active, double* __restrict__ f,
+                                                                double* __restrict__ f_x, double* __restrict__ f_u,
+                                                                const long batch, const int T) {
+    const int lane = threadIdx.x;
+    const int j = lane & 15;                                   // seed direction / Jacobian column
+    const long pt = (long)blockIdx.x * 4 + (lane >> 4);        // point index = traj * T + k
+    const long npts = batch * T;
+    if (pt >= npts) return;
+    const long traj = pt / T;
+    const int k = (int)(pt - traj * T);
+    if (active && active[traj] == 0) return;
+    const int n = md.n, m = md.m;
+    if (j >= n + m) return;
+    const double* xk = xTraj + (traj * (T + 1) + k) * n;
+    const double* uk = uTraj + pt * m;
+    Dual x[MAXN], u[MAXM], xn[MAXN];
+#pragma unroll
+    for (int i = 0; i < MAXN; ++i) x[i] = Dual{(i < n) ? xk[i] : 0.0, (i == j) ? 1.0 : 0.0};
+#pragma unroll
+    for (int i = 0; i < MAXM; ++i) u[i] = Dual{(i < m) ? uk[i] : 0.0, (n + i == j) ? 1.0 : 0.0};
+    model_step<Dual>(md, x, u, xn);
+    if (j < n) {
+        double* o = f_x + pt * n * n + j;
+#pragma unroll
+        for (int i = 0; i < MAXN; ++i)
+            if (i < n) o[i * n] = xn[i].d;
+    } else {
+        double* o = f_u + pt * n * m + (j - n);
+#pragma unroll
+        for (int i = 0; i < MAXN; ++i)
+            if (i < n) o[i * m] = xn[i].d;
+    }
+    if (f && j == 0) {
+#pragma unroll
+        for (int i = 0; i < MAXN; ++i)
+            if (i < n) f[pt * n + i] = xn[i].v;
+    }
+}
+
+// one thread per (trajectory, step) point plus one per trajectory for the terminal expansion
+__global__ __launch_bounds__(256) void quadratize_cost_kernel(const zm_quadcost_t cs, const int n, const int m,
+                                                              const double* __restrict__ xTraj,
+                                                              const double* __restrict__ uTraj,
+                                                              const int* __restrict__ active, double* __restrict__ c,
+                                                              double* __restrict__ c_x, double* __restrict__ c_u,
+                                                              double* __restrict__ v, double* __restrict__ v_x,
+                                                              const long batch, const int T) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long npts = batch * T;
+    if (id >= npts + batch) return;
+    const bool terminal = id >= npts;
+    const long traj = terminal ? (id - npts) : (id / T);
+    if (active && active[traj] == 0) return;
+    const int k = terminal ? T : (int)(id - traj * T);
+    const double* xk = xTraj + (traj * (T + 1) + k) * n;
+    double x[MAXN], u[MAXM];
+#pragma unroll
+    for (int i = 0; i < MAXN; ++i) x[i] = (i < n) ? xk[i] : 0.0;
+    const double* Qm = terminal ? cs.Qf : cs.Q;
+    double* gx = terminal ? (v_x ? v_x + traj * n : nullptr) : (c_x ? c_x + id * n : nullptr);
+    if (gx) {
+#pragma unroll
+        for (int jj = 0; jj < MAXN; ++jj) {
+            if (jj < n) {
+                double s = 0.0;   // ((Q + Q^T) x)[jj]
+#pragma unroll
+                for (int i = 0; i < MAXN; ++i)
+                    if (i < n) s = __builtin_fma(Qm[jj * n + i] + Qm[i * n + jj], x[i], s);
+                gx[jj] = s;
+            }
+        }
+    }
+    if (terminal) {
+        if (v) v[traj] = terminal_cost(cs, n, x);
+        return;
+    }
+    const double* uk = uTraj + id * m;
+#pragma unroll
+    for (int i = 0; i < MAXM; ++i) u[i] = (i < m) ? uk[i] : 0.0;
+    if (c_u) {
+#pragma unroll
+        for (int jj = 0; jj < MAXM; ++jj) {
+            if (jj < m) {
+                double s = 0.0;
+#pragma unroll
+                for (int i = 0; i < MAXM; ++i)
+                    if (i < m) s = __builtin_fma(cs.R[jj * m + i] + cs.R[i * m + jj], u[i], s);
+                c_u[id * m + jj] = s;
+            }
+        }
+    }
+    if (c) c[id] = running_cost(cs, n, m, x, u);
+}
+
+__global__ __launch_bounds__(256) void cost_hessians_kernel(const zm_quadcost_t cs, const int n, const int m,
+                                                            double* __restrict__ c_xx, double* __restrict__ c_ux,
+                                                            double* __restrict__ c_uu, double* __restrict__ v_xx) {
+    const int t = threadIdx.x;
+    if (t < n * n) {
+        const int i = t / n, jj = t % n;
+        if (c_xx) c_xx[t] = cs.Q[i * n + jj] + cs.Q[jj * n + i];
+        if (v_xx) v_xx[t] = cs.Qf[i * n + jj] + cs.Qf[jj * n + i];
+    }
+    if (t < m * m && c_uu) {
+        const int i = t / m, jj = t % m;
+        c_uu[t] = cs.R[i * m + jj] + cs.R[jj * m + i];
+    }
+    if (t < m * n && c_ux) c_ux[t] = 0.0;
+}
+
+}  // namespace zm
+
+static int zm_check_model(const zm_model_t* model, zm_model_t& md, const char* who) {
+    if (!model) return zm::set_error(ZM_EINVAL, "%s: null model", who);
+    md = *model;
+    if (md.kind == ZM_MODEL_QUADCOPTER) {
+        md.n = 12;
+        md.m = 4;
+    } else if (md.kind == ZM_MODEL_LINEAR) {
+        if (!md.A || !md.B) return zm::set_error(ZM_EINVAL, "%s: linear model needs A, B", who);
+    } else {
+        return zm::set_error(ZM_EUNSUPPORTED, "%s: unknown model kind %d", who, md.kind);
+    }
+    if (md.n < 1 || md.n > zm::MAXN || md.m < 1 || md.m > zm::MAXM)
+        return zm::set_error(ZM_EUNSUPPORTED, "%s: (n=%d, m=%d) not covered (n<=12, m<=4)", who, md.n, md.m);
+    return ZM_OK;
+}
+
+extern "C" int zm_linearize_dynamics_f64(const zm_model_t* model, const double* xTraj, const double* uTraj,
+                                         const int32_t* active, double* f, double* f_x, double* f_u, int64_t batch, int T,
+                                         void* stream) {
+    zm_model_t md;
+    int rc = zm_check_model(model, md, "zm_linearize_dynamics_f64");
+    if (rc) return rc;
+    if (!xTraj || !uTraj || !f_x || !f_u) return zm::set_error(ZM_EINVAL, "zm_linearize_dynamics_f64: null pointer");
+    if (batch < 0 || T < 1) return zm::set_error(ZM_EINVAL, "zm_linearize_dynamics_f64: bad size");
+    if (batch == 0) return ZM_OK;
+    const long npts = (long)batch * T;
+    hipLaunchKernelGGL(zm::linearize_dynamics_kernel, dim3((unsigned)((npts + 3) / 4)), dim3(64), 0, (hipStream_t)stream, md,
+                       xTraj, uTraj, (const int*)active, f, f_x, f_u, (long)batch, T);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+
+extern "C" int zm_quadratize_cost_f64(const zm_quadcost_t* cost, int n, int m, const double* xTraj, const double* uTraj,
+                                      const int32_t* active, double* c, double* c_x, double* c_u, double* v, double* v_x,
+                                      double* c_xx, double* c_ux, double* c_uu, double* v_xx, int64_t batch, int T,
+                                      void* stream) {
+    if (!cost || !cost->Q || !cost->R || !cost->Qf || !xTraj || !uTraj)
+        return zm::set_error(ZM_EINVAL, "zm_quadratize_cost_f64: null pointer");
+    if (n < 1 || n > zm::MAXN || m < 1 || m > zm::MAXM)
+        return zm::set_error(ZM_EUNSUPPORTED, "zm_quadratize_cost_f64: (n=%d, m=%d) not covered", n, m);
+    if (batch < 0 || T < 1) return zm::set_error(ZM_EINVAL, "zm_quadratize_cost_f64: bad size");
+    hipStream_t st = (hipStream_t)stream;
+    if (c_xx || c_ux || c_uu || v_xx)
+        hipLaunchKernelGGL(zm::cost_hessians_kernel, dim3(1), dim3(256), 0, st, *cost, n, m, c_xx, c_ux, c_uu, v_xx);
+    if (batch > 0 && (c || c_x || c_u || v || v_x)) {
+        const long work = (long)batch * T + batch;
+        hipLaunchKernelGGL(zm::quadratize_cost_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, *cost, n, m,
+                           xTraj, uTraj, (const int*)active, c, c_x, c_u, v, v_x, (long)batch, T);
+    }
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}

@@ -130,3 +130,169 @@ def forwardPass2(x0, dynFun, costFun, policy, trajPrev):
     if not arr.is_torch(J) and np.ndim(J) == 0:
         J = float(J)
     return traj, J
+
+
+def ensurePositiveDefinite(a, eps=1e-3):
+    """`w, v = eigh(a); (v * max(w, eps)) @ v.T` (reference ilqrUtils.py:217-219; eigh symmetrises its input).
+    `a` is (..., k, k) with k <= 16; returns a new array."""
+    shp = _shape(a)
+    if len(shp) < 2 or shp[-1] != shp[-2]:
+        raise ValueError("a must be (..., k, k)")
+    k = shp[-1]
+    d = arr.to_device(a, torch.float64).clone()
+    count = 1
+    for s_ in shp[:-2]:
+        count *= int(s_)
+    rc = _lib.lib().zm_psd_project_f64(d.data_ptr(), count, k, float(eps), ctypes.c_void_p(arr.stream_ptr(d)))
+    _lib.check(rc, "ensurePositiveDefinite")
+    return arr.result_like(d, a)
+
+
+def conditionQuadraticCost(quadratic_cost):
+    """Ensure quadratic cost is strictly positive definite (reference ilqrUtils.py:222-234): project the stacked
+    Hessian [[c_xx, c_ux^T],[c_ux, c_uu]] of every time step and slice it back."""
+    c, c_x, c_u, c_xx, c_ux, c_uu = _fields(quadratic_cost)
+    shp = _shape(c_ux)
+    m, n = shp[-2:]
+    lead = shp[:-2]
+    if _shape(c_xx) != lead + (n, n) or _shape(c_uu) != lead + (m, m):
+        raise ValueError("inconsistent cost Hessian shapes")
+    dxx, dux, duu = (arr.to_device(X, torch.float64).clone() for X in (c_xx, c_ux, c_uu))
+    count = 1
+    for s_ in lead:
+        count *= int(s_)
+    rc = _lib.lib().zm_condition_cost_f64(dxx.data_ptr(), dux.data_ptr(), duu.data_ptr(), count, n, m, 1e-3,
+                                          ctypes.c_void_p(arr.stream_ptr(dxx)))
+    _lib.check(rc, "conditionQuadraticCost")
+    return QuadraticCostFunction(c, c_x, c_u, arr.result_like(dxx, c_xx), arr.result_like(dux, c_ux),
+                                 arr.result_like(duu, c_uu))
+
+
+def conditionValueFunction(Vf):
+    """reference ilqrUtils.py:254-257."""
+    v, v_x, v_xx = _fields(Vf)
+    return QuadraticValueFunction(v, v_x, ensurePositiveDefinite(v_xx))
+
+
+def _registered_cost(runningCost, terminalCost):
+    """Accepts a zopt_amd.models.QuadraticCost handle (for both arguments) or its bound methods."""
+    for c in (runningCost, getattr(runningCost, "__self__", None)):
+        if isinstance(c, _models.QuadraticCost):
+            other = terminalCost if isinstance(terminalCost, _models.QuadraticCost) else getattr(terminalCost, "__self__", None)
+            if other is not c:
+                raise TypeError("runningCost and terminalCost must come from the same QuadraticCost")
+            return c
+    raise TypeError("runningCost / terminalCost must be a registered zopt_amd.models.QuadraticCost (or its "
+                    ".runningCost / .terminalCost methods); arbitrary Python callables cannot run inside a HIP kernel")
+
+
+def iterativeLqr(dynamics, runningCost, terminalCost, x0, uGuess, maxIter=100, tol=1e-3):
+    """Iterative LQR algorithm (reference ilqrUtils.py:260-327), batched and device-resident.
+
+    Arguments
+    ---------
+        dynamics : registered discrete model `xOut = f(x,u)` (zopt_amd.models.LinearModel / QuadcopterEuler)
+        runningCost, terminalCost : a registered zopt_amd.models.QuadraticCost (the handle, or its two methods)
+        x0 : (..., n) initial state(s)
+        uGuess : (..., N, m) initial guess for the control trajectory
+        maxIter : maximum number of iLQR iterations
+        tol : convergence tolerance `abs(J_prev - J) <= tol` (per trajectory)
+
+    Returns
+    -------
+        traj : Trajectory(xTraj (..., N+1, n), uTraj (..., N, m))
+        L : (..., N, m, n) feedback gains: `u[k] = L[k] @ (x[k]-xTraj[k]) + uTraj[k]`
+        J : (...) cost
+        converged : (...) bool
+
+    Per iteration (ilqrUtils.py:305-322): linearise along the trajectory, expand the cost, PD-condition the cost and
+    terminal Hessians (they are trajectory-independent for a quadratic cost: done once, shared), backward pass,
+    16-way line-search rollout, `converged = |J - J_new| <= tol`.  Converged trajectories drop out of later iterations
+    (the reference under vmap would run every lane to the slowest).
+    """
+    model = dynamics
+    if not hasattr(model, "c_struct"):
+        raise TypeError("dynamics must be a registered device model (zopt_amd.models.*)")
+    cost = _registered_cost(runningCost, terminalCost)
+    n, m = model.n, model.m
+    shp = _shape(uGuess)
+    lead, (N, mm) = shp[:-2], shp[-2:]
+    if mm != m or _shape(x0) != lead + (n,):
+        raise ValueError(f"x0 {_shape(x0)} / uGuess {shp} do not match the model (n={n}, m={m})")
+    dt = torch.float64
+    lib = _lib.lib()
+    dx0 = arr.to_device(x0, dt).reshape(-1, n).contiguous()
+    l = arr.to_device(uGuess, dt).reshape(-1, N, m).clone()          # policy = (uGuess, 0)          (:293)
+    dev = dx0.device
+    B = dx0.shape[0]
+    st = ctypes.c_void_p(arr.stream_ptr(dx0))
+    L = torch.zeros((B, N, m, n), dtype=dt, device=dev)
+    xT = torch.zeros((B, N + 1, n), dtype=dt, device=dev)            # traj_prev = zeros               (:294)
+    uT = torch.zeros((B, N, m), dtype=dt, device=dev)
+    xT2, uT2 = torch.empty_like(xT), torch.empty_like(uT)
+    J, Jn = torch.empty(B, dtype=dt, device=dev), torch.empty(B, dtype=dt, device=dev)
+    md, cs = model.c_struct(), cost.c_struct()
+    pmd, pcs = ctypes.addressof(md), ctypes.addressof(cs)
+    one = torch.ones(1, dtype=dt, device=dev)
+    alphas = torch.as_tensor(LINESEARCH_ALPHAS, dtype=dt, device=dev)
+
+    # initial rollout (alpha = 1) and its cost                                                       (:297-298)
+    _lib.check(lib.zm_rollout_linesearch_f64(pmd, pcs, dx0.data_ptr(), l.data_ptr(), L.data_ptr(), xT.data_ptr(),
+                                             uT.data_ptr(), one.data_ptr(), 1, None, xT2.data_ptr(), uT2.data_ptr(),
+                                             J.data_ptr(), None, B, N, st), "iterativeLqr: initial rollout")
+    xT, xT2 = xT2, xT
+    uT, uT2 = uT2, uT
+
+    # trajectory-independent Hessians of the quadratic cost, PD-conditioned once                     (:309-313)
+    c_xx = torch.empty((n, n), dtype=dt, device=dev)
+    c_ux = torch.empty((m, n), dtype=dt, device=dev)
+    c_uu = torch.empty((m, m), dtype=dt, device=dev)
+    v_xx = torch.empty((n, n), dtype=dt, device=dev)
+    _lib.check(lib.zm_quadratize_cost_f64(pcs, n, m, xT.data_ptr(), uT.data_ptr(), None, None, None, None, None, None,
+                                          c_xx.data_ptr(), c_ux.data_ptr(), c_uu.data_ptr(), v_xx.data_ptr(), 0, N, st),
+               "iterativeLqr: cost Hessians")
+    _lib.check(lib.zm_condition_cost_f64(c_xx.data_ptr(), c_ux.data_ptr(), c_uu.data_ptr(), 1, n, m, 1e-3, st),
+               "iterativeLqr: conditionQuadraticCost")
+    _lib.check(lib.zm_psd_project_f64(v_xx.data_ptr(), 1, n, 1e-3, st), "iterativeLqr: conditionValueFunction")
+
+    f_x = torch.empty((B, N, n, n), dtype=dt, device=dev)
+    f_u = torch.empty((B, N, n, m), dtype=dt, device=dev)
+    c_x = torch.empty((B, N, n), dtype=dt, device=dev)
+    c_u = torch.empty((B, N, m), dtype=dt, device=dev)
+    v_x = torch.empty((B, n), dtype=dt, device=dev)
+    converged = torch.zeros(B, dtype=torch.bool, device=dev)
+    active = torch.ones(B, dtype=torch.int32, device=dev)
+    it = 0
+    while it < maxIter and bool(active.any()):                                                        # (:301-303)
+        ap = active.data_ptr()
+        _lib.check(lib.zm_linearize_dynamics_f64(pmd, xT.data_ptr(), uT.data_ptr(), ap, None, f_x.data_ptr(),
+                                                 f_u.data_ptr(), B, N, st), "iterativeLqr: linearize")
+        _lib.check(lib.zm_quadratize_cost_f64(pcs, n, m, xT.data_ptr(), uT.data_ptr(), ap, None, c_x.data_ptr(),
+                                              c_u.data_ptr(), None, v_x.data_ptr(), None, None, None, None, B, N, st),
+                   "iterativeLqr: quadratize")
+        _lib.check(lib.zm_ilqr_backward_ex_f64(f_x.data_ptr(), f_u.data_ptr(), c_x.data_ptr(), c_u.data_ptr(),
+                                               c_xx.data_ptr(), c_ux.data_ptr(), c_uu.data_ptr(), v_x.data_ptr(),
+                                               v_xx.data_ptr(), ap, 1, l.data_ptr(), L.data_ptr(), B, N, n, m, st),
+                   "iterativeLqr: backward pass")
+        _lib.check(lib.zm_rollout_linesearch_f64(pmd, pcs, dx0.data_ptr(), l.data_ptr(), L.data_ptr(), xT.data_ptr(),
+                                                 uT.data_ptr(), alphas.data_ptr(), 16, ap, xT2.data_ptr(),
+                                                 uT2.data_ptr(), Jn.data_ptr(), None, B, N, st),
+                   "iterativeLqr: forward pass")
+        act = active.bool()
+        converged = torch.where(act, (J - Jn).abs() <= tol, converged)                               # (:318)
+        J = torch.where(act, Jn, J)
+        xT = torch.where(act[:, None, None], xT2, xT)
+        uT = torch.where(act[:, None, None], uT2, uT)
+        active = (~converged).to(torch.int32)
+        it += 1
+    tmpl = uGuess
+    fp32_in = (arr.is_torch(tmpl) and tmpl.dtype == torch.float32) or \
+        (not arr.is_torch(tmpl) and np.asarray(tmpl).dtype == np.float32)
+    outs = [xT.reshape(lead + (N + 1, n)), uT.reshape(lead + (N, m)), L.reshape(lead + (N, m, n)), J.reshape(lead)]
+    if fp32_in:
+        outs = [o.to(torch.float32) for o in outs]
+    xo, uo, Lo, Jo = (arr.result_like(o, tmpl) for o in outs)
+    co = arr.result_like(converged.reshape(lead), tmpl)
+    if not arr.is_torch(tmpl) and len(lead) == 0:
+        Jo, co = float(Jo), bool(co)
+    return Trajectory(xo, uo), Lo, Jo, co
