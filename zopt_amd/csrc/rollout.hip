@@ -12,6 +12,8 @@
 #include "models.h"
 #include "zm_common.h"
 
+#include <cstdlib>
+
 namespace zm {
 
 // one rollout; STORE: write xTraj/uTraj; returns J (0 when cost == nullptr)
@@ -126,6 +128,12 @@ __global__ __launch_bounds__(64) void rollout_linesearch_kernel(const zm_model_t
     }
 }
 
+// rollout_fast.hip: compile-time (n, m) = (12, 4), 16 step sizes
+int rollout_fast_dispatch(const zm_model_t& md, const double* Q, const double* R, const double* Qf, const double* x0,
+                          const double* l, const double* L, const double* xPrev, const double* uPrev,
+                          const double* alphas, const int* active, double* xTraj, double* uTraj, double* J, int* idx,
+                          int64_t batch, int T, hipStream_t st);
+
 }  // namespace zm
 
 extern "C" int zm_rollout_linesearch_f64(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0,
@@ -157,6 +165,13 @@ extern "C" int zm_rollout_linesearch_f64(const zm_model_t* model, const zm_quadc
     zm_quadcost_t cs = cost ? *cost : zm_quadcost_t{nullptr, nullptr, nullptr};
     const bool hc = cost != nullptr;
     const int* act = (const int*)active;
+    static const bool force_generic = [] {
+        const char* e = getenv("ZOPT_AMD_ROLLOUT_PATH");
+        return e && e[0] == 'g';
+    }();
+    if (!force_generic && n_alpha == 16 && md.n == 12 && md.m == 4 && cost && T >= 1)
+        return zm::rollout_fast_dispatch(md, cs.Q, cs.R, cs.Qf, x0, l, L, xPrev, uPrev, alphas, act, xTraj, uTraj, J,
+                                         (int*)alpha_idx, batch, T, st);
     if (n_alpha == 1) {
         const unsigned blocks = (unsigned)((batch + 63) / 64);
         hipLaunchKernelGGL((zm::rollout_linesearch_kernel<1>), dim3(blocks), dim3(64), 0, st, md, cs, hc, x0, l, L, xPrev,

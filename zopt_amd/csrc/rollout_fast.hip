@@ -1,0 +1,309 @@
+// K6 (fast path)  rollout_linesearch for compile-time (model, n = 12, m = 4), 16 step sizes -- gfx950.
+//
+// Same arithmetic as rollout.hip (reference ilqrUtils.py:33-66, 116-150; pytrees.py:49-52, 215-220); what changes:
+//  * compile-time model / dimensions: no predicated loops, no branches on the model kind;
+//  * a step's policy data [l_k | L_k | xPrev_k | uPrev_k] (68 doubles) is fetched ONCE per trajectory by the 16 lanes of
+//    its group with coalesced loads, one step ahead, into an LDS double buffer; the lanes then read it by broadcast
+//    (the generic kernel issued 68 redundant global loads per lane and step);
+//  * cost matrices (and A, B of a linear model) live in LDS; diagonal Q, R, Qf (the demos' weights) use 12 + 4 FMAs;
+//  * the alpha = 1 lane stores its rollout speculatively during pass 1: pass 2 (re-roll of the winner) only runs for
+//    trajectories whose argmin is another step size.
+#include "models.h"
+#include "zm_common.h"
+
+namespace zm {
+
+constexpr int RN = 12, RM = 4;
+constexpr int PSZ = RM + RM * RN + RN + RM;  // 68 doubles of policy data per step
+
+struct FastArgs {
+    const double* A;      // linear model (device) or nullptr
+    const double* B;
+    double dt;
+    const double* Q;      // full (n,n) / (m,m) / (n,n) matrices
+    const double* R;
+    const double* Qf;
+    const double* x0;
+    const double* l;
+    const double* L;
+    const double* xPrev;
+    const double* uPrev;
+    const double* alphas;
+    const int* active;
+    double* xTraj;
+    double* uTraj;
+    double* J;
+    int* idx;
+    long batch;
+    int T;
+};
+
+template <int KIND>
+__device__ __forceinline__ void fast_step(const double* As, const double* Bs, const double dt,
+                                          const double (&x)[RN], const double (&u)[RM], double (&xn)[RN]) {
+    if constexpr (KIND == ZM_MODEL_QUADCOPTER) {
+        // quad_inertial_dynamics<double> with sincos (tan = sin/cos): models.h / quadcopter.py:23-144
+        constexpr double g = 9.807, mass = 2.5;
+        double sphi, cphi, sth, cth, spsi, cpsi;
+        sincos(x[6], &sphi, &cphi);
+        sincos(x[7], &sth, &cth);
+        sincos(x[8], &spsi, &cpsi);
+        const double tth = sth / cth;
+        const double fa0 = -0.2 * x[0] + -0.05 * (x[0] * x[0]);
+        const double fa1 = -0.2 * x[1] + -0.05 * (x[1] * x[1]);
+        const double fa2 = -0.3 * x[2] + -0.1 * (x[2] * x[2]);
+        const double ft0 = fa0 + (mass * g) * (-sth);
+        const double ft1 = fa1 + (mass * g) * (sphi * cth);
+        const double ft2 = ((mass * (-u[0])) + fa2) + (mass * g) * (cphi * cth);
+        const double c0 = x[4] * x[2] - x[5] * x[1];
+        const double c1 = x[5] * x[0] - x[3] * x[2];
+        const double c2 = x[3] * x[1] - x[4] * x[0];
+        double xd[RN];
+        xd[0] = (1.0 / mass) * (ft0 - c0);
+        xd[1] = (1.0 / mass) * (ft1 - c1);
+        xd[2] = (1.0 / mass) * (ft2 - c2);
+        xd[3] = u[1] + -0.1 * x[3];
+        xd[4] = u[2] + -0.1 * x[4];
+        xd[5] = u[3] + -0.05 * x[5];
+        xd[6] = (x[3] + (sphi * tth) * x[4]) + (cphi * tth) * x[5];
+        xd[7] = cphi * x[4] - sphi * x[5];
+        xd[8] = (sphi / cth) * x[4] + (cphi / cth) * x[5];
+        xd[9] = ((cth * cpsi) * x[0] + (sphi * sth * cpsi - cphi * spsi) * x[1]) + (cphi * sth * cpsi - sphi * spsi) * x[2];
+        xd[10] = ((cth * spsi) * x[0] + (sphi * sth * spsi + cphi * cpsi) * x[1]) + (cphi * sth * spsi - sphi * cpsi) * x[2];
+        xd[11] = ((-sth) * x[0] + (sphi * cth) * x[1]) + (cphi * cth) * x[2];
+#pragma unroll
+        for (int i = 0; i < RN; ++i) xn[i] = x[i] + dt * xd[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < RN; ++i) {
+            double ax = x[0] * As[i * RN];
+#pragma unroll
+            for (int j = 1; j < RN; ++j) ax = ax + x[j] * As[i * RN + j];
+            double bu = u[0] * Bs[i * RM];
+#pragma unroll
+            for (int j = 1; j < RM; ++j) bu = bu + u[j] * Bs[i * RM + j];
+            xn[i] = ax + bu;
+            __builtin_amdgcn_sched_barrier(0);  // one row of A, B in flight at a time (see quad_form)
+        }
+    }
+}
+
+template <bool DIAG, int K>
+__device__ __forceinline__ double quad_form(const double* W, const double (&z)[K]) {
+    double acc = 0.0;
+    if constexpr (DIAG) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc = __builtin_fma(z[j] * W[j * K + j], z[j], acc);   // (z^T W)_j = z_j W_jj
+    } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) s = __builtin_fma(z[i], W[i * K + j], s);
+            acc = __builtin_fma(s, z[j], acc);
+            // keep the LDS reads of column j+1 behind this column's arithmetic: without the fence the scheduler
+            // clusters all K*K table reads up front (hundreds of live VGPRs, spills)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    return acc;
+}
+
+// cooperative fetch of one step's policy data of this lane's trajectory: element e = a + 16 i of [l|L|xPrev|uPrev]
+struct PolPtrs {
+    const double* p[5];
+    int st[5];
+};
+
+template <int KIND, bool DIAG>
+// (no __restrict__ on the LDS tables: with it the loop-invariant LDS reads of Q, A, B ... are hoisted into registers --
+//  several hundred VGPRs -- instead of being re-read by broadcast every step)
+__device__ __forceinline__ void rollout_ls_body(const FastArgs& g, const double* Qs, const double* Rs, const double* Qfs,
+                                                const double* As, const double* Bs, double (*pol)[4][PSZ + 4]) {
+    const int lane = threadIdx.x;
+    const int grp = lane >> 4, a = lane & 15;
+    const long traj = (long)blockIdx.x * 4 + grp;
+    const bool live = (traj < g.batch) && (g.active == nullptr || g.active[traj < g.batch ? traj : 0] != 0);
+    const long t = live ? traj : 0;
+    const int T = g.T;
+    const double alpha = g.alphas[a];
+
+    PolPtrs pp;
+    {
+        const double* lt = g.l + t * T * RM;
+        const double* Lt = g.L + t * T * RM * RN;
+        const double* xpt = g.xPrev + t * (T + 1) * RN;
+        const double* upt = g.uPrev + t * T * RM;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int e = a + 16 * i;
+            if (e < RM) {
+                pp.p[i] = lt + e;
+                pp.st[i] = RM;
+            } else if (e < RM + RM * RN) {
+                pp.p[i] = Lt + (e - RM);
+                pp.st[i] = RM * RN;
+            } else if (e < RM + RM * RN + RN) {
+                pp.p[i] = xpt + (e - RM - RM * RN);
+                pp.st[i] = RN;
+            } else if (e < PSZ) {
+                pp.p[i] = upt + (e - RM - RM * RN - RN);
+                pp.st[i] = RM;
+            } else {  // lanes a >= 4 of the 5th load: re-read element 0 of uPrev_k into the buffer's padding
+                pp.p[i] = upt;
+                pp.st[i] = RM;
+            }
+        }
+    }
+    const double* x0t = g.x0 + t * RN;
+    double* xo = g.xTraj + t * (T + 1) * RN;
+    double* uo = g.uTraj + t * T * RM;
+
+    // one rollout of step size `al`; STORE: this lane writes xTraj / uTraj
+    auto rollout = [&](const double al, const bool store) -> double {
+        double x[RN], u[RM], xn[RN], nx[5];
+#pragma unroll
+        for (int i = 0; i < RN; ++i) x[i] = x0t[i];
+        if (store) {
+#pragma unroll
+            for (int i = 0; i < RN; ++i) xo[i] = x[i];
+        }
+        // stage step 0
+        {
+            double v0[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) v0[i] = *pp.p[i];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int e = a + 16 * i;
+                if (e < PSZ + 4) pol[0][grp][e] = v0[i];
+            }
+        }
+        double J = 0.0;
+        for (int k = 0; k < T; ++k) {
+            const int cur = k & 1;
+            const bool more = (k + 1 < T);
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) nx[i] = pp.p[i][(long)(k + 1) * pp.st[i]];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const double* pk = pol[cur][grp];
+            // u = (alpha * l_k + L_k (x - xPrev_k)) + uPrev_k            (pytrees.py:220, ilqrUtils.py:59-60)
+            double dx[RN];
+#pragma unroll
+            for (int j = 0; j < RN; ++j) dx[j] = x[j] - pk[RM + RM * RN + j];
+#pragma unroll
+            for (int i = 0; i < RM; ++i) {
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < RN; ++j) s = __builtin_fma(pk[RM + i * RN + j], dx[j], s);
+                u[i] = (al * pk[i] + s) + pk[RM + RM * RN + RN + i];
+                __builtin_amdgcn_sched_barrier(0);  // one row of L_k in flight at a time
+            }
+            J += quad_form<DIAG, RN>(Qs, x) + quad_form<DIAG, RM>(Rs, u);
+            fast_step<KIND>(As, Bs, g.dt, x, u, xn);
+#pragma unroll
+            for (int i = 0; i < RN; ++i) x[i] = xn[i];
+            if (store) {
+#pragma unroll
+                for (int i = 0; i < RM; ++i) uo[(long)k * RM + i] = u[i];
+#pragma unroll
+                for (int i = 0; i < RN; ++i) xo[(long)(k + 1) * RN + i] = x[i];
+            }
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const int e = a + 16 * i;
+                    if (e < PSZ + 4) pol[cur ^ 1][grp][e] = nx[i];
+                }
+            }
+        }
+        J += quad_form<DIAG, RN>(Qfs, x);
+        return J;
+    };
+
+    // pass 0: every lane its own step size; lane a == 0 (alpha_0) stores speculatively.
+    // pass 1 (only where another step size than alpha_0 won): every lane of the group re-rolls the winner, lane 0 stores.
+    double al = alpha;
+    bool store = live && a == 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        const double J = rollout(al, store);
+        if (pass == 1) break;
+        double key = live ? J : __builtin_inf();
+        int isn = (live && (J != J)) ? 1 : 0;
+        int who = a;
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            const double ok = __shfl_xor(key, off);
+            const int on = __shfl_xor(isn, off);
+            const int ow = __shfl_xor(who, off);
+            const bool better = (on > isn) || (on == isn && ((on == 0 && ok < key) || ((on == 1 || ok == key) && ow < who)));
+            key = better ? ok : key;
+            isn = better ? on : isn;
+            who = better ? ow : who;
+        }
+        const int best = who;
+        const double Jbest = __shfl(J, (grp << 4) + best);
+        if (live && a == 0) {
+            if (g.J) g.J[t] = Jbest;
+            if (g.idx) g.idx[t] = best;
+        }
+        const bool need2 = live && best != 0;
+        if (__ballot(need2) == 0ull) break;
+        al = g.alphas[best];
+        store = need2 && a == 0;
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(64) void rollout_ls_fast_kernel(const FastArgs g) {
+    __shared__ double Qs[RN * RN], Rs[RM * RM], Qfs[RN * RN];
+    __shared__ double As[KIND == ZM_MODEL_LINEAR ? RN * RN : 1], Bs[KIND == ZM_MODEL_LINEAR ? RN * RM : 1];
+    __shared__ double pol[2][4][PSZ + 4];
+    const int lane = threadIdx.x;
+    bool offdiag = false;
+    for (int e = lane; e < RN * RN; e += 64) {
+        const double q = g.Q[e], qf = g.Qf[e];
+        Qs[e] = q;
+        Qfs[e] = qf;
+        offdiag |= (e / RN != e % RN) && (q != 0.0 || qf != 0.0);
+    }
+    for (int e = lane; e < RM * RM; e += 64) {
+        const double r = g.R[e];
+        Rs[e] = r;
+        offdiag |= (e / RM != e % RM) && (r != 0.0);
+    }
+    if constexpr (KIND == ZM_MODEL_LINEAR) {
+        for (int e = lane; e < RN * RN; e += 64) As[e] = g.A[e];
+        for (int e = lane; e < RN * RM; e += 64) Bs[e] = g.B[e];
+    }
+    __syncthreads();
+    // diagonal weights (the demos' Q = I, R = I, Qf = 10 I): x^T W x costs n FMAs instead of n^2; decided per launch,
+    // wave-uniform
+    if (__ballot(offdiag) == 0ull)
+        rollout_ls_body<KIND, true>(g, Qs, Rs, Qfs, As, Bs, pol);
+    else
+        rollout_ls_body<KIND, false>(g, Qs, Rs, Qfs, As, Bs, pol);
+}
+
+template <int KIND>
+static int launch_fast(const FastArgs& g, hipStream_t st) {
+    hipLaunchKernelGGL((rollout_ls_fast_kernel<KIND>), dim3((unsigned)((g.batch + 3) / 4)), dim3(64), 0, st, g);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+
+// Fast path dispatch: (n, m) = (12, 4), 16 step sizes.
+int rollout_fast_dispatch(const zm_model_t& md, const double* Q, const double* R, const double* Qf,
+                          const double* x0, const double* l, const double* L, const double* xPrev, const double* uPrev,
+                          const double* alphas, const int* active, double* xTraj, double* uTraj, double* J, int* idx,
+                          int64_t batch, int T, hipStream_t st) {
+    FastArgs g{md.A, md.B, md.dt, Q, R, Qf, x0, l, L, xPrev, uPrev, alphas, active, xTraj, uTraj, J, idx, (long)batch, T};
+    if (md.kind == ZM_MODEL_QUADCOPTER) return launch_fast<ZM_MODEL_QUADCOPTER>(g, st);
+    return launch_fast<ZM_MODEL_LINEAR>(g, st);
+}
+
+}  // namespace zm
