@@ -49,7 +49,19 @@ int zm_lqr_backward_supported(int n, int m, int elem_size);
 int zm_lqr_backward_f64(const double* A, const double* B, const double* Q, const double* R, double* L,
                         int64_t batch, int T, int n, int m, void* stream);
 
-/* Same, HOST pointers (NumPy arrays): allocates device staging, copies in, solves, copies L back. */
+/* Finite-horizon LQR with bilinear cost (cross term H), affine dynamics (offset d) and linear costs (q, r).
+ * Replaces: zopt/lqrUtils.py:207-262  bilinearAffineLqr(A, B, d, Q, R, H, q, r, q0, N) -> (L, l)
+ *     carry (V, v) <- (Q[T-1], q[T-1]);  Su = r + v^T B + d^T V B   Suu = R + B^T V B   Sux = H + B^T V A   (:244-246)
+ *     L = solve(Suu, Sux)  l = solve(Suu, Su)  V' = Q + A^T V A - L^T Suu L  v' = q + A^T (v + V d) - Sux^T l  (:248-252)
+ * (q0 / v0 never influence L or l and are not taken.)          control law u = -L x - l
+ * in : A (batch,T,n,n) B (batch,T,n,m) d (batch,T,n) Q (batch,T,n,n) R (batch,T,m,m) H (batch,T,m,n) q (batch,T,n) r (batch,T,m)
+ * out: L (batch,T,m,n)  l (batch,T,m)
+ */
+int zm_lqr_backward_affine_f64(const double* A, const double* B, const double* d, const double* Q, const double* R,
+                               const double* H, const double* q, const double* r, double* L, double* l,
+                               int64_t batch, int T, int n, int m, void* stream);
+
+/* zm_lqr_backward_f64 with HOST pointers (NumPy arrays): allocates device staging, copies in, solves, copies L back. */
 int zm_lqr_backward_host_f64(const double* A, const double* B, const double* Q, const double* R, double* L,
                              int64_t batch, int T, int n, int m);
 

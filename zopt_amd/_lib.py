@@ -27,6 +27,8 @@ SYMBOLS = {
                                            ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "zm_lqr_backward_host_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, ctypes.c_int64, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int]),
+    "zm_lqr_backward_affine_f64": (ctypes.c_int, [_c_dp] * 10 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                                 ctypes.c_void_p]),
     "zm_ilqr_backward_f64": (ctypes.c_int, [_c_dp] * 11 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                            ctypes.c_void_p]),
     # (model*, cost*, x0, l, L, xPrev, uPrev, alphas, n_alpha, active, xTraj, uTraj, J, alpha_idx, batch, T, stream)

@@ -18,6 +18,15 @@
 //     T1 = Q_uu L (1 MFMA),  v_xx' = Q_xx - L^T T1 (1 MFMA, negated A operand)
 // 2*KS + 2 MFMAs per step.  Inputs are read once with 8-byte loads straight into their register layouts, two steps
 // ahead (register double buffer).  Shapes: n <= 12, m <= 4.
+//
+// MODE 1 = K2 lqr_backward_affine: the same sweep for zopt/lqrUtils.py:207-262 (bilinearAffineLqr), i.e. with
+//     f_x,f_u <- A,B   c_xx,c_ux,c_uu <- Q,H,R   c_x,c_u <- q,r   and the affine-dynamics offset d:
+//     Su  = r + B^T (v + V^T d)      Suu = R + B^T V B      Sux = H + B^T V A                       (:244-246)
+//     L = solve(Suu, Sux)   l = solve(Suu, Su)       (no sign flip; law u = -L x - l)                (:248-249)
+//     V' = Q + A^T V A - L^T Suu L      v' = q + A^T (v + V d) - Sux^T l                             (:251-252)
+// (v0 / q0 never influence L or l and are not carried.)  V d is a row reduction of the V registers (4 xor-shuffles per
+// K-step), V^T d a column reduction (2 shuffles) re-laid out through LDS; both are kept apart so that a
+// nonsymmetric V is treated exactly as the reference does.
 #include "tile16_f64.h"
 #include "zm_common.h"
 
@@ -29,6 +38,8 @@ struct IlqrStepRegs {
     double C[KS];   // c_xx[4s+g][c]
     double Cu;      // row NP+g of the stacked cost Hessian: c_ux[g][c] (c < n) | c_uu[g][c-NP] | identity padding
     double cv;      // [c_x ; c_u][c]  (column-indexed)
+    double dc;      // MODE 1: d[c]       (column-indexed)
+    double dr[KS];  // MODE 1: d[4s+g]    (row-indexed)
 };
 
 template <int KS>
@@ -37,13 +48,15 @@ struct IlqrAddr {
     const double* pC0;   // K-step s adds (rowok ? s*4n : 0)
     const double* pCu;
     const double* pcv;
+    const double* pdc;   // MODE 1
+    const double* pdr0;  // MODE 1: K-step s adds (rowok ? 4 s : 0)
     double* pOut;        // L_k[g][c] (c < n) or l_k[g] (c == NP)
-    int dF, dC, sF, sC, sCu, scv, sOut;
+    int dF, dC, sF, sC, sCu, scv, sOut, sd;
     bool rowok[KS], vF[KS], vC[KS], vCu, vcv, vOut, vL, cA;
     double cu_pad;
 };
 
-template <int KS>
+template <int KS, int MODE>
 __device__ __forceinline__ void ilqr_load_step(IlqrStepRegs<KS>& d, IlqrAddr<KS>& a) {
     double f[KS], cc[KS];
 #pragma unroll
@@ -63,12 +76,30 @@ __device__ __forceinline__ void ilqr_load_step(IlqrStepRegs<KS>& d, IlqrAddr<KS>
     }
     d.Cu = a.vCu ? cu : a.cu_pad;
     d.cv = a.vcv ? cv : 0.0;
+    if constexpr (MODE == 1) {
+        const double dc = *a.pdc;
+        double dr[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) dr[s] = a.pdr0[a.rowok[s] ? 4 * s : 0];
+        a.pdc -= a.sd;
+        a.pdr0 -= a.sd;
+        d.dc = a.cA ? dc : 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) d.dr[s] = a.rowok[s] ? dr[s] : 0.0;
+    }
 }
 
 // LDS per wave (doubles): [0,64) tile rows 0..3 = [Q_ux | Q_uu]; [64,80) row 4 = q; [80,96) v_x' (column-indexed)
-constexpr int ILQR_LDS_DOUBLES = 96;
+//                       MODE 1: [96,112) V^T d (column-indexed); [112,116) l
+constexpr int ILQR_LDS_DOUBLES = 116;
 
-template <int KS, bool PREFETCH>
+__device__ __forceinline__ void ilqr_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int KS, int MODE, bool PREFETCH>
 __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], IlqrStepRegs<KS>& d, IlqrAddr<KS>& a,
                                           double* sm, const int g, const int c, const int ob0, const int ob1,
                                           const int ob2, const int ob3, const int oqa) {
@@ -84,14 +115,36 @@ __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], 
     gacc[KS] = d.Cu;
 #pragma unroll
     for (int s = 0; s < KS; ++s) gacc = mfma(y[s], d.F[s], gacc);
-    // q[c] = cv[c] + sum_k F[k][c] v_x[k]   (partial over this lane's rows, then over the 4 lane groups)
+    // q[c] = cv[c] + sum_k F[k][c] w[k]   (partial over this lane's rows, then over the 4 lane groups);
+    // MODE 0: w = v_x.  MODE 1: w = v + V d under the state columns (A^T (v + V d), :252) and v + V^T d under the
+    // control columns (v^T B + d^T V B, :244).
     double qp = 0.0;
+    if constexpr (MODE == 1) {
+        double vtd = 0.0;  // (V^T d)[c]: column reduction
 #pragma unroll
-    for (int s = 0; s < KS; ++s) qp = __builtin_fma(d.F[s], vxr[s], qp);
+        for (int s = 0; s < KS; ++s) vtd = __builtin_fma(Vxx[s], d.dr[s], vtd);
+        vtd += __shfl_xor(vtd, 16);
+        vtd += __shfl_xor(vtd, 32);
+        if (g == 0) sm[96 + c] = a.cA ? vtd : 0.0;
+        ilqr_lds_sync();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            double vd = Vxx[s] * d.dc;  // (V d)[4s+g]: row reduction over the 16 lanes of the group
+            vd += __shfl_xor(vd, 1);
+            vd += __shfl_xor(vd, 2);
+            vd += __shfl_xor(vd, 4);
+            vd += __shfl_xor(vd, 8);
+            const double w = vxr[s] + (a.cA ? vd : sm[96 + 4 * s + g]);
+            qp = __builtin_fma(d.F[s], w, qp);
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) qp = __builtin_fma(d.F[s], vxr[s], qp);
+    }
     qp += __shfl_xor(qp, 16);
     qp += __shfl_xor(qp, 32);
     const double qv = d.cv + qp;
-    if constexpr (PREFETCH) ilqr_load_step(d, a);
+    if constexpr (PREFETCH) ilqr_load_step<KS, MODE>(d, a);
 
     // solve: tile + q row through LDS
     sm[g * 16 + c] = gacc[KS];
@@ -112,18 +165,31 @@ __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], 
     b[3] = sm[ob3];
     const double quu_a = sm[oqa];  // Q_uu[c][g]: A operand of Q_uu L (0-padded through the address choice below)
     __builtin_amdgcn_wave_barrier();
+    const double b0[4] = {b[0], b[1], b[2], b[3]};  // original right-hand side (Sux column) for MODE 1's v' update
     if (!__all(lu_solve4_nopivot(S, b, x))) lu_solve4(S, b, x);
     const double x01 = (g & 1) ? x[1] : x[0];
     const double x23 = (g & 1) ? x[3] : x[2];
-    const double out = -((g & 2) ? x23 : x01);  // L_k[g][c] for c < n, l_k[g] for c == NP
+    const double xg = (g & 2) ? x23 : x01;
+    const double out = (MODE == 1) ? xg : -xg;  // L_k[g][c] for c < n, l_k[g] for c == NP
     if (a.vOut) *a.pOut = out;
     a.pOut -= a.sOut;
     const double lv = a.vL ? out : 0.0;
 
-    // v_x'[c] = Q_x[c] + sum_i L[i][c] Q_u[i]      (= Q_x - L^T Q_uu l with Q_uu l = -Q_u)
     double vxn = qv;
+    if constexpr (MODE == 1) {
+        // v'[c] = (q + A^T (v + V d))[c] - sum_i Sux[i][c] l[i]                                   (lqrUtils.py:252)
+        if (g == 0 && c == NP) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) vxn = __builtin_fma(-x[i], qu[i], vxn);
+            for (int i = 0; i < 4; ++i) sm[112 + i] = x[i];
+        }
+        ilqr_lds_sync();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vxn = __builtin_fma(-b0[i], sm[112 + i], vxn);
+    } else {
+        // v_x'[c] = Q_x[c] + sum_i L[i][c] Q_u[i]      (= Q_x - L^T Q_uu l with Q_uu l = -Q_u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vxn = __builtin_fma(-x[i], qu[i], vxn);
+    }
     if (g == 0) sm[80 + c] = a.cA ? vxn : 0.0;
     // T1 = Q_uu L ;  v_xx' = Q_xx - L^T T1
     const d4 t1 = mfma(quu_a, lv, zero4());
@@ -133,21 +199,19 @@ __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], 
     vacc = mfma<true>(lv, t1[0], vacc);
 #pragma unroll
     for (int s = 0; s < KS; ++s) Vxx[s] = vacc[s];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    ilqr_lds_sync();
 #pragma unroll
     for (int s = 0; s < KS; ++s) vxr[s] = sm[80 + 4 * s + g];
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int KS>
+template <int KS, int MODE>
 __global__ __launch_bounds__(64) void ilqr_backward_t16_f64(
     const double* __restrict__ f_x, const double* __restrict__ f_u, const double* __restrict__ c_x,
     const double* __restrict__ c_u, const double* __restrict__ c_xx, const double* __restrict__ c_ux,
     const double* __restrict__ c_uu, const double* __restrict__ vf_x, const double* __restrict__ vf_xx,
-    const int* __restrict__ active, const int shared_h, double* __restrict__ lout, double* __restrict__ Lout,
-    const int T, const int n, const int m) {
+    const double* __restrict__ dvec, const long svx, const long svxx, const int* __restrict__ active,
+    const int shared_h, double* __restrict__ lout, double* __restrict__ Lout, const int T, const int n, const int m) {
     constexpr int NP = 4 * KS;
     const int lane = threadIdx.x;
     const long traj = blockIdx.x;
@@ -193,6 +257,12 @@ __global__ __launch_bounds__(64) void ilqr_backward_t16_f64(
     a.vcv = cA || cB;
     a.pcv = cA ? (cxt + c) : cB ? (cut + (c - NP)) : cxt;
     a.scv = cB ? m : n;
+    if constexpr (MODE == 1) {
+        const double* dt_ = dvec + last * n;
+        a.pdc = cA ? (dt_ + c) : dt_;
+        a.pdr0 = row0 ? (dt_ + g) : dt_;
+        a.sd = n;
+    }
     a.vL = (g < m) && cA;
     const bool vl = (g < m) && (c == NP);
     a.vOut = a.vL || vl;
@@ -212,8 +282,8 @@ __global__ __launch_bounds__(64) void ilqr_backward_t16_f64(
     // terminal value function
     double Vxx[KS], vxr[KS];
     {
-        const double* vxx = shared_h ? vf_xx : vf_xx + traj * nn;
-        const double* vx = vf_x + traj * n;
+        const double* vxx = shared_h ? vf_xx : vf_xx + traj * svxx;
+        const double* vx = vf_x + traj * svx;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int row = 4 * s + g;
@@ -226,27 +296,57 @@ __global__ __launch_bounds__(64) void ilqr_backward_t16_f64(
     }
 
     IlqrStepRegs<KS> d0, d1;
-    ilqr_load_step(d0, a);
-    if (T >= 2) ilqr_load_step(d1, a);
+    ilqr_load_step<KS, MODE>(d0, a);
+    if (T >= 2) ilqr_load_step<KS, MODE>(d1, a);
     int k = T - 1;
     while (k >= 3) {
-        ilqr_step<KS, true>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
-        ilqr_step<KS, true>(Vxx, vxr, d1, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
+        ilqr_step<KS, MODE, true>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
+        ilqr_step<KS, MODE, true>(Vxx, vxr, d1, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
         k -= 2;
     }
     if (k == 2) {
-        ilqr_step<KS, true>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
-        ilqr_step<KS, false>(Vxx, vxr, d1, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
-        ilqr_step<KS, false>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
+        ilqr_step<KS, MODE, true>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
+        ilqr_step<KS, MODE, false>(Vxx, vxr, d1, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
+        ilqr_step<KS, MODE, false>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
     } else if (k == 1) {
-        ilqr_step<KS, false>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
-        ilqr_step<KS, false>(Vxx, vxr, d1, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
+        ilqr_step<KS, MODE, false>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
+        ilqr_step<KS, MODE, false>(Vxx, vxr, d1, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
     } else {
-        ilqr_step<KS, false>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
+        ilqr_step<KS, MODE, false>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
     }
 }
 
 }  // namespace zm
+
+namespace zm {
+template <int MODE>
+static int launch_ilqr(const double* f_x, const double* f_u, const double* c_x, const double* c_u, const double* c_xx,
+                       const double* c_ux, const double* c_uu, const double* vf_x, const double* vf_xx, const double* d,
+                       long svx, long svxx, const int* act, int sh, double* l, double* L, int64_t batch, int T, int n, int m,
+                       hipStream_t st) {
+    const dim3 grid((unsigned)batch), block(64);
+    if (n <= 4)
+        hipLaunchKernelGGL((ilqr_backward_t16_f64<1, MODE>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
+                           vf_xx, d, svx, svxx, act, sh, l, L, T, n, m);
+    else if (n <= 8)
+        hipLaunchKernelGGL((ilqr_backward_t16_f64<2, MODE>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
+                           vf_xx, d, svx, svxx, act, sh, l, L, T, n, m);
+    else
+        hipLaunchKernelGGL((ilqr_backward_t16_f64<3, MODE>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
+                           vf_xx, d, svx, svxx, act, sh, l, L, T, n, m);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+}  // namespace zm
+
+static int zm_check_sweep_args(const char* who, int64_t batch, int T, int n, int m) {
+    if (batch < 0 || T < 1 || n < 1 || m < 1)
+        return zm::set_error(ZM_EINVAL, "%s: bad size batch=%lld T=%d n=%d m=%d", who, (long long)batch, T, n, m);
+    if (n > 12 || m > 4) return zm::set_error(ZM_EUNSUPPORTED, "%s: (n=%d, m=%d) not covered (need n<=12, m<=4)", who, n, m);
+    if ((int64_t)T * n * n >= (int64_t)1 << 31 || batch >= ((int64_t)1 << 31))
+        return zm::set_error(ZM_EUNSUPPORTED, "%s: T*n*n or batch too large", who);
+    return ZM_OK;
+}
 
 extern "C" int zm_ilqr_backward_ex_f64(const double* f_x, const double* f_u, const double* c_x, const double* c_u,
                                        const double* c_xx, const double* c_ux, const double* c_uu, const double* vf_x,
@@ -254,29 +354,11 @@ extern "C" int zm_ilqr_backward_ex_f64(const double* f_x, const double* f_u, con
                                        double* L, int64_t batch, int T, int n, int m, void* stream) {
     if (!f_x || !f_u || !c_x || !c_u || !c_xx || !c_ux || !c_uu || !vf_x || !vf_xx || !l || !L)
         return zm::set_error(ZM_EINVAL, "zm_ilqr_backward_f64: null pointer");
-    if (batch < 0 || T < 1 || n < 1 || m < 1)
-        return zm::set_error(ZM_EINVAL, "zm_ilqr_backward_f64: bad size batch=%lld T=%d n=%d m=%d", (long long)batch, T,
-                             n, m);
-    if (n > 12 || m > 4)
-        return zm::set_error(ZM_EUNSUPPORTED, "zm_ilqr_backward_f64: (n=%d, m=%d) not covered (need n<=12, m<=4)", n, m);
-    if ((int64_t)T * n * n >= (int64_t)1 << 31 || batch >= ((int64_t)1 << 31))
-        return zm::set_error(ZM_EUNSUPPORTED, "zm_ilqr_backward_f64: T*n*n or batch too large");
+    const int rc = zm_check_sweep_args("zm_ilqr_backward_f64", batch, T, n, m);
+    if (rc) return rc;
     if (batch == 0) return ZM_OK;
-    hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)batch), block(64);
-    const int* act = (const int*)active;
-    const int sh = shared_hessian ? 1 : 0;
-    if (n <= 4)
-        hipLaunchKernelGGL((zm::ilqr_backward_t16_f64<1>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
-                           vf_xx, act, sh, l, L, T, n, m);
-    else if (n <= 8)
-        hipLaunchKernelGGL((zm::ilqr_backward_t16_f64<2>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
-                           vf_xx, act, sh, l, L, T, n, m);
-    else
-        hipLaunchKernelGGL((zm::ilqr_backward_t16_f64<3>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
-                           vf_xx, act, sh, l, L, T, n, m);
-    ZM_HIP_CHECK(hipGetLastError());
-    return ZM_OK;
+    return zm::launch_ilqr<0>(f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, (long)n, (long)n * n,
+                              (const int*)active, shared_hessian ? 1 : 0, l, L, batch, T, n, m, (hipStream_t)stream);
 }
 
 extern "C" int zm_ilqr_backward_f64(const double* f_x, const double* f_u, const double* c_x, const double* c_u,
@@ -285,4 +367,19 @@ extern "C" int zm_ilqr_backward_f64(const double* f_x, const double* f_u, const 
                                     void* stream) {
     return zm_ilqr_backward_ex_f64(f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, 0, l, L, batch, T, n, m,
                                    stream);
+}
+
+extern "C" int zm_lqr_backward_affine_f64(const double* A, const double* B, const double* d, const double* Q,
+                                          const double* R, const double* H, const double* q, const double* r, double* L,
+                                          double* l, int64_t batch, int T, int n, int m, void* stream) {
+    if (!A || !B || !d || !Q || !R || !H || !q || !r || !L || !l)
+        return zm::set_error(ZM_EINVAL, "zm_lqr_backward_affine_f64: null pointer");
+    const int rc = zm_check_sweep_args("zm_lqr_backward_affine_f64", batch, T, n, m);
+    if (rc) return rc;
+    if (batch == 0) return ZM_OK;
+    // carry (V, v) <- (Q[T-1], q[T-1])   (lqrUtils.py:261): terminal pointers into the last step, trajectory stride T*size
+    const double* vf_xx = Q + (int64_t)(T - 1) * n * n;
+    const double* vf_x = q + (int64_t)(T - 1) * n;
+    return zm::launch_ilqr<1>(A, B, q, r, Q, H, R, vf_x, vf_xx, d, (long)T * n, (long)T * n * n, nullptr, 0, l, L, batch, T,
+                              n, m, (hipStream_t)stream);
 }

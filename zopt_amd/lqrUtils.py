@@ -71,6 +71,57 @@ def discreteFiniteHorizonLqr(A, B, Q, R, N):
     return arr.result_like(dL, A)
 
 
+def bilinearAffineLqr(A, B, d, Q, R, H, q, r, q0, N):
+    """Finite Horizon LQR with bilinear cost and affine dynamics (reference lqrUtils.py:207-262).
+
+    Arguments
+    ---------
+        A : (..., N, n, n)    B : (..., N, n, m)    d : (..., N, n)
+        Q : (..., N, n, n)    R : (..., N, m, m)    H : (..., N, m, n)
+        q : (..., N, n)       r : (..., N, m)       q0 : (..., N)   (does not influence the gains, accepted for parity)
+        N : horizon depth
+
+    Returns
+    -------
+        L : (..., N, m, n) optimal lqr gains `L[k]`
+        l : (..., N, m) optimal lqr offsets `l[k]`          (law `u = -L x - l`, demos/bilinearLqrControl.py:14)
+    """
+    shp = tuple(B.shape) if hasattr(B, "shape") else tuple(np.shape(B))
+    if len(shp) < 3:
+        _shape_error("B must have shape (..., N, n, m)")
+    n, m = shp[-2:]
+    lead = shp[:-3]
+    spec = (("A", A, (n, n)), ("B", B, (n, m)), ("d", d, (n,)), ("Q", Q, (n, n)), ("R", R, (m, m)), ("H", H, (m, n)),
+            ("q", q, (n,)), ("r", r, (m,)))
+    for name, X, tail in spec:
+        s_ = tuple(X.shape) if hasattr(X, "shape") else tuple(np.shape(X))
+        if s_[len(s_) - len(tail):] != tail or len(s_) != len(lead) + 1 + len(tail) or s_[:len(lead)] != lead or s_[len(lead)] < N:
+            _shape_error(f"{name} has shape {s_}, expected {lead + ('>=N',) + tail} with N={N}")
+    if N < 1:
+        _shape_error("N must be >= 1")
+    dt = torch.float64
+    dev = []
+    for name, X, tail in spec:
+        t = arr.to_device(X, dt)
+        if t.shape[len(lead)] != N:
+            t = t.narrow(len(lead), 0, N).contiguous()
+        dev.append(t)
+    dA, dB, dd, dQ, dR, dH, dq, dr = dev
+    batch = 1
+    for s_ in lead:
+        batch *= int(s_)
+    dL = torch.empty(lead + (N, m, n), dtype=dt, device=dA.device)
+    dl = torch.empty(lead + (N, m), dtype=dt, device=dA.device)
+    rc = _lib.lib().zm_lqr_backward_affine_f64(dA.data_ptr(), dB.data_ptr(), dd.data_ptr(), dQ.data_ptr(), dR.data_ptr(),
+                                               dH.data_ptr(), dq.data_ptr(), dr.data_ptr(), dL.data_ptr(), dl.data_ptr(),
+                                               batch, N, n, m, ctypes.c_void_p(arr.stream_ptr(dA)))
+    _lib.check(rc, "bilinearAffineLqr")
+    fp32_in = (arr.is_torch(A) and A.dtype == torch.float32) or (not arr.is_torch(A) and np.asarray(A).dtype == np.float32)
+    if fp32_in:
+        dL, dl = dL.to(torch.float32), dl.to(torch.float32)
+    return arr.result_like(dL, A), arr.result_like(dl, A)
+
+
 def proportionalFeedbackController(x, x0, u0, K):
     """`u = -K (x - x0) + u0` (reference lqrUtils.py:266-269); no controller states."""
     control = -K @ (x - x0) + u0
