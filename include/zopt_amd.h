@@ -157,6 +157,36 @@ int zm_psd_project_f64(double* A, int64_t count, int k, double eps, void* stream
 int zm_condition_cost_f64(double* c_xx, double* c_ux, double* c_uu, int64_t count, int n, int m, double eps,
                           void* stream);
 
+/* ---- box-constrained LQ-MPC (reference: zopt/mpcUtils.py:12-81, class lqrMpc; the reference hands this QP to
+ *      cvxpy -> OSQP, whose arithmetic is not in the reference tree: numeric parity is "unpinned", acceptance is by KKT
+ *      residuals -- see DESIGN.md) -------------------------------------------------------------------------------
+ *   min  sum_{k<N} (x_k'Q x_k + u_k'R u_k) + x_N'Qf x_N        (mpcUtils.py:52-54, no 1/2)
+ *   s.t. x_{k+1} = A x_k + B u_k,  x_lb <= x_k <= x_ub (k = 0..N),  u_lb <= u_k <= u_ub,  x_0 = x0      (:55-58)
+ * Method: ADMM on the splitting {dynamics-feasible trajectory w} / {box copy y}; the w-update is an LQ tracking
+ * problem solved exactly by a Riccati factorisation that does not depend on the iterates (zm_mpc_setup_f64, once per
+ * problem), so one ADMM iteration is an affine backward sweep + a forward rollout + a clip.
+ */
+#define ZM_MPC_OPTIMAL 1            /* cvxpy status "optimal"            */
+#define ZM_MPC_INFEASIBLE 2         /* "infeasible"                      */
+#define ZM_MPC_USER_LIMIT 3         /* "user_limit" (max_iter reached)   */
+
+/* Riccati tables of the ADMM w-update for penalty rho:  K (N,m,n), Minv (N,m,m)   [all device pointers]
+ * in : A (n,n) B (n,m) Q (n,n) R (m,m) Qf (n,n) */
+int zm_mpc_setup_f64(const double* A, const double* B, const double* Q, const double* R, const double* Qf, double rho,
+                     int N, int n, int m, double* K, double* Minv, void* stream);
+
+/* Solve `batch` instances (one per initial state) of the QP above.
+ * in : A, B (shared), K, Minv from zm_mpc_setup_f64 (same rho), bounds x_lb, x_ub (n), u_lb, u_ub (m) (+-inf allowed),
+ *      x0 (batch,n); workspace: 4 * batch * N * (n+m) doubles
+ * out: xTraj (batch,N+1,n)  uTraj (batch,N,m)  status (batch) ZM_MPC_*  iters (batch) or NULL
+ *      resid (batch,2) = final (primal, dual) residual inf-norms, or NULL
+ */
+int zm_mpc_solve_f64(const double* A, const double* B, const double* K, const double* Minv, const double* x_lb,
+                     const double* x_ub, const double* u_lb, const double* u_ub, const double* x0, double rho,
+                     double eps_abs, double eps_rel, double eps_prim_inf, int max_iter, double* workspace, double* xTraj,
+                     double* uTraj,
+                     int32_t* status, int32_t* iters, double* resid, int64_t batch, int N, int n, int m, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,13 @@ SYMBOLS = {
     # (f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, active, shared_hessian, l, L, batch, T, n, m, stream)
     "zm_ilqr_backward_ex_f64": (ctypes.c_int, [_c_dp] * 10 + [ctypes.c_int] + [_c_dp] * 2 +
                                 [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    # (A, B, Q, R, Qf, rho, N, n, m, K, Minv, stream)
+    "zm_mpc_setup_f64": (ctypes.c_int, [_c_dp] * 5 + [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_dp, _c_dp,
+                                                    ctypes.c_void_p]),
+    # (A, B, K, Minv, x_lb, x_ub, u_lb, u_ub, x0, rho, eps_abs, eps_rel, max_iter, ws, xTraj, uTraj, status, iters, resid,
+    #  batch, N, n, m, stream)
+    "zm_mpc_solve_f64": (ctypes.c_int, [_c_dp] * 9 + [ctypes.c_double] * 4 + [ctypes.c_int] + [_c_dp] * 6 +
+                         [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "zm_psd_project_f64": (ctypes.c_int, [_c_dp, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
     "zm_condition_cost_f64": (ctypes.c_int, [_c_dp] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                                           ctypes.c_void_p]),

@@ -1,0 +1,411 @@
+// K9  mpc_box_qp -- batched box-constrained LQ-MPC, fp64, gfx950.
+//
+// Problem statement: zopt/mpcUtils.py:48-59 (class lqrMpc).  The reference solves it with cvxpy -> OSQP (ADMM on a
+// sparse KKT system), code that is not part of the reference tree; this is an MI355X-first ADMM for the same QP:
+//
+//   split   w = (x_1..x_N, u_0..u_{N-1})  consistent with x_{k+1} = A x_k + B u_k, x_0 = x0      (dynamics, exact)
+//           y = copy of w inside the box [lb, ub]                                                  (bounds, exact)
+//   iterate w <- argmin cost(w) + rho/2 |w - (y - lam)|^2  s.t. dynamics     (LQ tracking problem)
+//           y <- clip(w + lam, lb, ub);   lam <- lam + w - y
+//
+// The w-update's Riccati matrices depend on (A, B, Q, R, Qf, rho) only -- not on x0, y, lam -- so they are factored
+// ONCE (mpc_setup_kernel: K_k, Suu_k^-1), shared by every instance and every iteration.  One ADMM iteration is then
+//   backward:  p <- -rho z_N;  k = N-1..0:  Qu = -rho zu_k + B^T p;  kf_k = Suu_k^-1 Qu;  p <- hx_k + A^T p - K_k^T Qu
+//   forward :  x <- x0;        k = 0..N-1:  u = -K_k x - kf_k;  x <- A x + B u;  y, lam update, residuals
+// = ~500 FMAs per stage, no factorisation, no branching on data.
+//
+// Mapping: ONE LANE per MPC instance (instances are independent: mpcUtils.py:76-81); the shared tables are read at
+// wave-uniform addresses (scalar loads), x and p live in registers, the iterates y, lam, kf in a batch-minor
+// workspace (lane i <-> consecutive addresses: coalesced).  Each lane runs its own ADMM to convergence
+// (OSQP-style criteria); a wave retires when all its lanes have.
+//
+// Termination (as OSQP): r_prim = |w - y|_inf <= eps_abs + eps_rel max(|w|,|y|),  r_dual = rho |y - y_prev|_inf <=
+// eps_abs + eps_rel rho |lam|.  Infeasibility: x0 outside its bounds; or, every 25 iterations, OSQP's primal
+// infeasibility certificate on the dual step v = w - y:  |G^T v|_inf <= eps_pinf |v|_inf  (G = the linear map u -> w;
+// computed by an adjoint sweep) and  v^T w(u=0) - support_box(v) > eps_pinf |v|_inf,  i.e. v separates the dynamics
+// subspace from the box.  The certificate is sound but can need thousands of iterations; an infeasible instance that
+// is not certified within max_iter reports "user_limit".
+#include "zm_common.h"
+
+namespace zm {
+
+// ----------------------------------------------------------------------------------------------------------------
+// setup: single workgroup, matrices in LDS, threads spread over matrix elements
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int SN = 12, SM = 4;
+
+__device__ __forceinline__ void mm_nn(double* C, const double* A, const double* B, int p, int q, int r) {  // C = A(p,q) B(q,r)
+    for (int e = threadIdx.x; e < p * r; e += blockDim.x) {
+        const int i = e / r, j = e % r;
+        double s = 0.0;
+        for (int k = 0; k < q; ++k) s = __builtin_fma(A[i * q + k], B[k * r + j], s);
+        C[e] = s;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void mm_tn(double* C, const double* A, const double* B, int q, int p, int r) {  // C = A(q,p)^T B(q,r)
+    for (int e = threadIdx.x; e < p * r; e += blockDim.x) {
+        const int i = e / r, j = e % r;
+        double s = 0.0;
+        for (int k = 0; k < q; ++k) s = __builtin_fma(A[k * p + i], B[k * r + j], s);
+        C[e] = s;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void mpc_setup_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                        const double* __restrict__ Q, const double* __restrict__ R,
+                                                        const double* __restrict__ Qf, const double rho, const int N,
+                                                        const int n, const int m, double* __restrict__ Kout,
+                                                        double* __restrict__ Minvout) {
+    __shared__ double As[SN * SN], Bs[SN * SM], P[SN * SN], PA[SN * SN], PB[SN * SM], Sux[SM * SN], Suu[SM * SM],
+        Mi[SM * SM], K[SM * SN], T1[SN * SN], T2[SN * SN];
+    const int t = threadIdx.x;
+    for (int e = t; e < n * n; e += blockDim.x) {
+        As[e] = A[e];
+        P[e] = 2.0 * Qf[e] + ((e / n == e % n) ? rho : 0.0);  // P_N = 2 Qf + rho I   (1/2-form Hessian of x'Qf x + rho/2 |x-z|^2)
+    }
+    for (int e = t; e < n * m; e += blockDim.x) Bs[e] = B[e];
+    __syncthreads();
+    for (int k = N - 1; k >= 0; --k) {
+        mm_nn(PA, P, As, n, n, n);
+        mm_nn(PB, P, Bs, n, n, m);
+        mm_tn(Sux, Bs, PA, n, m, n);  // B^T P A
+        mm_tn(Suu, Bs, PB, n, m, m);  // B^T P B
+        if (t < m * m) Suu[t] += 2.0 * R[t] + ((t / m == t % m) ? rho : 0.0);
+        __syncthreads();
+        if (t == 0) {  // m x m inverse by Gauss-Jordan with partial pivoting (m <= 4)
+            double a[SM][2 * SM];
+            for (int i = 0; i < m; ++i)
+                for (int j = 0; j < m; ++j) {
+                    a[i][j] = Suu[i * m + j];
+                    a[i][m + j] = (i == j) ? 1.0 : 0.0;
+                }
+            for (int c = 0; c < m; ++c) {
+                int pv = c;
+                for (int i = c + 1; i < m; ++i)
+                    if (__builtin_fabs(a[i][c]) > __builtin_fabs(a[pv][c])) pv = i;
+                for (int j = 0; j < 2 * m; ++j) {
+                    const double tmp = a[c][j];
+                    a[c][j] = a[pv][j];
+                    a[pv][j] = tmp;
+                }
+                const double inv = 1.0 / a[c][c];
+                for (int j = 0; j < 2 * m; ++j) a[c][j] *= inv;
+                for (int i = 0; i < m; ++i)
+                    if (i != c) {
+                        const double f = a[i][c];
+                        for (int j = 0; j < 2 * m; ++j) a[i][j] = __builtin_fma(-f, a[c][j], a[i][j]);
+                    }
+            }
+            for (int i = 0; i < m; ++i)
+                for (int j = 0; j < m; ++j) Mi[i * m + j] = a[i][m + j];
+        }
+        __syncthreads();
+        mm_nn(K, Mi, Sux, m, m, n);     // K_k = Suu^-1 B^T P A
+        mm_tn(T1, As, PA, n, n, n);     // A^T P A
+        mm_tn(T2, Sux, K, m, n, n);     // Sux^T K
+        for (int e = t; e < n * n; e += blockDim.x)
+            P[e] = (2.0 * Q[e] + ((e / n == e % n) ? rho : 0.0)) + T1[e] - T2[e];
+        for (int e = t; e < m * n; e += blockDim.x) Kout[(long)k * m * n + e] = K[e];
+        for (int e = t; e < m * m; e += blockDim.x) Minvout[(long)k * m * m + e] = Mi[e];
+        __syncthreads();
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// solve: one lane per instance
+// ----------------------------------------------------------------------------------------------------------------
+struct MpcArgs {
+    const double* x0;
+    double rho, eps_abs, eps_rel, eps_pinf;
+    int max_iter;
+    double *ws, *xTraj, *uTraj;
+    int *status, *iters;
+    double* resid;
+    long batch;
+    int N;
+};
+
+// The shared tables are separate `const __restrict__` kernel arguments so that hipcc can prove them read-only and
+// fetch them with scalar loads (wave-uniform addresses) instead of per-lane vector loads held in hundreds of VGPRs.
+template <int NS, int MC>
+__global__ __launch_bounds__(64) void mpc_solve_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                       const double* __restrict__ Ktab, const double* __restrict__ Mtab,
+                                                       const double* __restrict__ x_lb, const double* __restrict__ x_ub,
+                                                       const double* __restrict__ u_lb, const double* __restrict__ u_ub,
+                                                       const MpcArgs g) {
+    constexpr int W = NS + MC;
+    const long inst = (long)blockIdx.x * 64 + threadIdx.x;
+    const bool live = inst < g.batch;
+    const long ii = live ? inst : 0;
+    const long bt = g.batch;
+    const int N = g.N;
+    const double rho = g.rho;
+    // workspace, batch-minor: y[k][i][inst], lam[k][i][inst], kf[k][j][inst] (+ spare), rv[k][i][inst]
+    double* y = g.ws;
+    double* lam = g.ws + (long)N * W * bt;
+    double* kf = g.ws + 2L * N * W * bt;
+    double* rv = g.ws + 3L * N * W * bt;
+
+    double x0[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) x0[i] = g.x0[ii * NS + i];
+    bool x0_ok = true;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) x0_ok &= (x0[i] >= x_lb[i]) && (x0[i] <= x_ub[i]);  // x_0 = x0 is box-constrained too (:56,:58)
+
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            y[((long)k * W + i) * bt + ii] = 0.0;
+            lam[((long)k * W + i) * bt + ii] = 0.0;
+            rv[((long)k * W + i) * bt + ii] = 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < MC; ++j) kf[((long)k * MC + j) * bt + ii] = 0.0;
+    }
+
+    int status = x0_ok ? 0 : ZM_MPC_INFEASIBLE;
+    int it = 0;  // this lane's ADMM iterations
+    double rp = 0.0, rd = 0.0;
+    bool done = !live || status != 0;
+    for (int gi = 0; gi < g.max_iter; ++gi) {  // gi is wave-uniform
+        if (__all(done)) break;
+        const bool chk = ((gi + 1) % 25) == 0;  // infeasibility certificate on this iteration
+        // ---- backward affine sweep: p <- -rho z_N; Qu = -rho zu_k + B^T p; kf_k = Suu_k^-1 Qu; p <- hx_k + A^T p - K_k^T Qu
+        double p[NS];
+        {
+            const long o = (long)(N - 1) * W;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) p[i] = -rho * (y[(o + i) * bt + ii] - lam[(o + i) * bt + ii]);
+        }
+        for (int k = N - 1; k >= 0; --k) {
+            const double* Kk = Ktab + (long)k * MC * NS;
+            const double* Mk = Mtab + (long)k * MC * MC;
+            double qu[MC];
+#pragma unroll
+            for (int j = 0; j < MC; ++j) {
+                const long e = ((long)k * W + NS + j) * bt + ii;
+                double sacc = -rho * (y[e] - lam[e]);
+#pragma unroll
+                for (int i = 0; i < NS; ++i) sacc = __builtin_fma(B[i * MC + j], p[i], sacc);
+                qu[j] = sacc;
+            }
+#pragma unroll
+            for (int j = 0; j < MC; ++j) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int l = 0; l < MC; ++l) sacc = __builtin_fma(Mk[j * MC + l], qu[l], sacc);
+                if (!done) kf[((long)k * MC + j) * bt + ii] = sacc;
+            }
+            double pn[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                double sacc = 0.0;
+                if (k >= 1) {
+                    const long e = ((long)(k - 1) * W + i) * bt + ii;  // the copy of x_k lives in stage k-1
+                    sacc = -rho * (y[e] - lam[e]);
+                }
+#pragma unroll
+                for (int l = 0; l < NS; ++l) sacc = __builtin_fma(A[l * NS + i], p[l], sacc);
+#pragma unroll
+                for (int j = 0; j < MC; ++j) sacc = __builtin_fma(-Kk[j * NS + i], qu[j], sacc);
+                pn[i] = sacc;
+            }
+#pragma unroll
+            for (int i = 0; i < NS; ++i) p[i] = pn[i];
+        }
+        // ---- forward rollout w, projection y, dual update lam, residual norms (and r = w - y, support function on chk)
+        double x[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x[i] = x0[i];
+        double nrp = 0.0, nrd = 0.0, nw = 0.0, ny = 0.0, nl = 0.0, sup = 0.0;
+        for (int k = 0; k < N; ++k) {
+            const double* Kk = Ktab + (long)k * MC * NS;
+            double u[MC], xn[NS];
+#pragma unroll
+            for (int j = 0; j < MC; ++j) {
+                double sacc = -kf[((long)k * MC + j) * bt + ii];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) sacc = __builtin_fma(-Kk[j * NS + i], x[i], sacc);
+                u[j] = sacc;
+            }
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int l = 0; l < NS; ++l) sacc = __builtin_fma(A[i * NS + l], x[l], sacc);
+#pragma unroll
+                for (int j = 0; j < MC; ++j) sacc = __builtin_fma(B[i * MC + j], u[j], sacc);
+                xn[i] = sacc;
+            }
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const double wv = (i < NS) ? xn[i < NS ? i : 0] : u[i >= NS ? i - NS : 0];
+                const double lo = (i < NS) ? x_lb[i < NS ? i : 0] : u_lb[i >= NS ? i - NS : 0];
+                const double hi = (i < NS) ? x_ub[i < NS ? i : 0] : u_ub[i >= NS ? i - NS : 0];
+                const long e = ((long)k * W + i) * bt + ii;
+                const double lold = lam[e], yold = y[e];
+                double yn = wv + lold;
+                yn = yn < lo ? lo : (yn > hi ? hi : yn);
+                const double r = wv - yn;
+                const double ln = lold + r;
+                if (!done) {
+                    y[e] = yn;
+                    lam[e] = ln;
+                    if (chk) rv[e] = r;
+                }
+                if (chk) sup += (r > 0.0) ? r * hi : ((r < 0.0) ? r * lo : 0.0);  // support function of the box at v = r
+                nrp = __builtin_fmax(nrp, __builtin_fabs(r));
+                nrd = __builtin_fmax(nrd, __builtin_fabs(yn - yold));
+                nw = __builtin_fmax(nw, __builtin_fabs(wv));
+                ny = __builtin_fmax(ny, __builtin_fabs(yn));
+                nl = __builtin_fmax(nl, __builtin_fabs(ln));
+            }
+#pragma unroll
+            for (int i = 0; i < NS; ++i) x[i] = xn[i];
+        }
+        bool need_cert = false;
+        if (!done) {
+            ++it;
+            rp = nrp;
+            rd = rho * nrd;
+            const double ep = g.eps_abs + g.eps_rel * __builtin_fmax(nw, ny);
+            const double ed = g.eps_abs + g.eps_rel * rho * nl;
+            if (rp <= ep && rd <= ed) {
+                status = ZM_MPC_OPTIMAL;
+                done = true;
+            } else if (!(rp == rp)) {
+                done = true;  // NaN iterates (non-finite data): stop with the limit status
+            } else {
+                need_cert = chk;
+            }
+        }
+        // ---- primal infeasibility certificate (see file header)
+        if (chk && __any(need_cert)) {
+            double sv[NS];
+            {
+                const long o = (long)(N - 1) * W;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) sv[i] = rv[(o + i) * bt + ii];
+            }
+            double gmax = 0.0;
+            for (int k = N - 1; k >= 0; --k) {
+#pragma unroll
+                for (int j = 0; j < MC; ++j) {
+                    double sacc = rv[((long)k * W + NS + j) * bt + ii];
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) sacc = __builtin_fma(B[i * MC + j], sv[i], sacc);
+                    gmax = __builtin_fmax(gmax, __builtin_fabs(sacc));  // (G^T r)_k = ru_k + B^T s
+                }
+                double sn[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    double sacc = (k >= 1) ? rv[((long)(k - 1) * W + i) * bt + ii] : 0.0;
+#pragma unroll
+                    for (int l = 0; l < NS; ++l) sacc = __builtin_fma(A[l * NS + i], sv[l], sacc);
+                    sn[i] = sacc;
+                }
+#pragma unroll
+                for (int i = 0; i < NS; ++i) sv[i] = sn[i];
+            }
+            double vw0 = 0.0;  // v^T w(u = 0) = s^T x0   (s = sum_j (A^j)^T vx_j after the sweep)
+#pragma unroll
+            for (int i = 0; i < NS; ++i) vw0 = __builtin_fma(sv[i], x0[i], vw0);
+            if (need_cert && gmax <= g.eps_pinf * rp && (vw0 - sup) > g.eps_pinf * rp) {
+                status = ZM_MPC_INFEASIBLE;
+                done = true;
+            }
+        }
+    }
+    // final trajectory: the dynamics-exact rollout w of the last iterate
+    if (live) {
+        double x[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            x[i] = x0[i];
+            g.xTraj[(ii * (N + 1)) * NS + i] = x[i];
+        }
+        for (int k = 0; k < N; ++k) {
+            const double* Kk = Ktab + (long)k * MC * NS;
+            double u[MC], xn[NS];
+#pragma unroll
+            for (int j = 0; j < MC; ++j) {
+                double sacc = -kf[((long)k * MC + j) * bt + ii];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) sacc = __builtin_fma(-Kk[j * NS + i], x[i], sacc);
+                u[j] = sacc;
+                g.uTraj[(ii * N + k) * MC + j] = sacc;
+            }
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int l = 0; l < NS; ++l) sacc = __builtin_fma(A[i * NS + l], x[l], sacc);
+#pragma unroll
+                for (int j = 0; j < MC; ++j) sacc = __builtin_fma(B[i * MC + j], u[j], sacc);
+                xn[i] = sacc;
+            }
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                x[i] = xn[i];
+                g.xTraj[(ii * (N + 1) + k + 1) * NS + i] = x[i];
+            }
+        }
+        g.status[ii] = status ? status : ZM_MPC_USER_LIMIT;
+        if (g.iters) g.iters[ii] = it;
+        if (g.resid) {
+            g.resid[ii * 2] = rp;
+            g.resid[ii * 2 + 1] = rd;
+        }
+    }
+}
+
+struct MpcTabs {
+    const double *A, *B, *K, *Minv, *x_lb, *x_ub, *u_lb, *u_ub;
+};
+
+template <int NS, int MC>
+static int launch_mpc(const MpcTabs& t, const MpcArgs& g, hipStream_t st) {
+    hipLaunchKernelGGL((mpc_solve_kernel<NS, MC>), dim3((unsigned)((g.batch + 63) / 64)), dim3(64), 0, st, t.A, t.B, t.K,
+                       t.Minv, t.x_lb, t.x_ub, t.u_lb, t.u_ub, g);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+
+}  // namespace zm
+
+extern "C" int zm_mpc_setup_f64(const double* A, const double* B, const double* Q, const double* R, const double* Qf,
+                                double rho, int N, int n, int m, double* K, double* Minv, void* stream) {
+    if (!A || !B || !Q || !R || !Qf || !K || !Minv) return zm::set_error(ZM_EINVAL, "zm_mpc_setup_f64: null pointer");
+    if (N < 1 || n < 1 || m < 1 || !(rho > 0.0)) return zm::set_error(ZM_EINVAL, "zm_mpc_setup_f64: bad size / rho");
+    if (n > zm::SN || m > zm::SM) return zm::set_error(ZM_EUNSUPPORTED, "zm_mpc_setup_f64: (n=%d, m=%d) not covered", n, m);
+    hipLaunchKernelGGL(zm::mpc_setup_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, A, B, Q, R, Qf, rho, N, n, m, K,
+                       Minv);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+
+extern "C" int zm_mpc_solve_f64(const double* A, const double* B, const double* K, const double* Minv,
+                                const double* x_lb, const double* x_ub, const double* u_lb, const double* u_ub,
+                                const double* x0, double rho, double eps_abs, double eps_rel, double eps_prim_inf,
+                                int max_iter, double* workspace, double* xTraj, double* uTraj, int32_t* status, int32_t* iters,
+                                double* resid, int64_t batch, int N, int n, int m, void* stream) {
+    if (!A || !B || !K || !Minv || !x_lb || !x_ub || !u_lb || !u_ub || !x0 || !workspace || !xTraj || !uTraj || !status)
+        return zm::set_error(ZM_EINVAL, "zm_mpc_solve_f64: null pointer");
+    if (batch < 0 || N < 1 || max_iter < 0 || !(rho > 0.0)) return zm::set_error(ZM_EINVAL, "zm_mpc_solve_f64: bad size");
+    if (batch == 0) return ZM_OK;
+    zm::MpcTabs t{A, B, K, Minv, x_lb, x_ub, u_lb, u_ub};
+    zm::MpcArgs g{x0, rho, eps_abs, eps_rel, eps_prim_inf, max_iter, workspace, xTraj, uTraj, (int*)status, (int*)iters, resid,
+                  (long)batch, N};
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 12 && m == 4) return zm::launch_mpc<12, 4>(t, g, st);
+    if (n == 8 && m == 4) return zm::launch_mpc<8, 4>(t, g, st);
+    if (n == 4 && m == 2) return zm::launch_mpc<4, 2>(t, g, st);
+    if (n == 4 && m == 1) return zm::launch_mpc<4, 1>(t, g, st);
+    if (n == 2 && m == 2) return zm::launch_mpc<2, 2>(t, g, st);
+    if (n == 2 && m == 1) return zm::launch_mpc<2, 1>(t, g, st);
+    if (n == 1 && m == 1) return zm::launch_mpc<1, 1>(t, g, st);
+    return zm::set_error(ZM_EUNSUPPORTED, "zm_mpc_solve_f64: (n=%d, m=%d) not among the compiled shapes", n, m);
+}

@@ -1,0 +1,134 @@
+"""Drop-in for the solve path of ``zopt.mpcUtils`` (class ``lqrMpc``) on MI355X HIP kernels.
+
+Same constructor and ``solve`` signature as the reference (mpcUtils.py:14-26, 61-81).  New: ``x0`` may carry leading
+batch axes -- every initial state is an independent QP instance solved by one GPU lane.  The plotting / animation helpers
+of the reference module (mpcUtils.py:84-202) are presentation code and not part of this package.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _arrays as arr
+from . import _lib
+from .pytrees import Trajectory
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+_STATUS = {1: "optimal", 2: "infeasible", 3: "user_limit"}
+
+
+class lqrMpc():
+
+    def __init__(self, A, B, Q, R, N, x_lb, x_ub, u_lb, u_ub, Qf=None):
+        """
+        Setup an LQR MPC problem (reference mpcUtils.py:14-59)
+
+        Arguments
+        ---------
+            A : Dynamics matrix; shape = (n,n)
+            B : Input matrix; shape = (n,m)
+            Q : State cost matrix; shape = (n,n)
+            R : Control cost matrix; shape = (m,m)
+            N : MPC horizon
+            x_lb, x_ub : State lower / upper bound (+-inf allowed)
+            u_lb, u_ub : Control lower / upper bound
+            Qf : Terminal cost matrix, optional; shape = (n,n).  Defaults to Q
+        """
+        if Qf is None:
+            Qf = Q
+        f64 = lambda X: np.ascontiguousarray(np.asarray(X, dtype=np.float64))
+        self.A, self.B, self.Q, self.R, self.Qf = f64(A), f64(B), f64(Q), f64(R), f64(Qf)
+        self.n, self.m = self.B.shape
+        self.N = int(N)
+        self.x_lb, self.x_ub, self.u_lb, self.u_ub = f64(x_lb), f64(x_ub), f64(u_lb), f64(u_ub)
+        if self.A.shape != (self.n, self.n) or self.Q.shape != (self.n, self.n) or self.R.shape != (self.m, self.m) \
+                or self.x_lb.shape != (self.n,) or self.u_lb.shape != (self.m,) or self.N < 1:
+            raise ValueError("inconsistent lqrMpc problem shapes")
+        self._dev = None
+        self._tables = {}
+        # one penalty for every instance: the geometric mean of the cost curvatures keeps both blocks of the
+        # w-update Hessian (2Q + rho I, 2R + rho I) comparably conditioned
+        self.rho = float(np.sqrt(max(np.trace(2 * self.Q) / self.n, 1e-12) * max(np.trace(2 * self.R) / self.m, 1e-12)))
+
+    def _device_problem(self, rho):
+        arr.require_gpu()
+        if self._dev is None:
+            self._dev = {k: arr.to_device(getattr(self, k), torch.float64)
+                         for k in ("A", "B", "Q", "R", "Qf", "x_lb", "x_ub", "u_lb", "u_ub")}
+        if rho not in self._tables:
+            d = self._dev
+            K = torch.empty((self.N, self.m, self.n), dtype=torch.float64, device=d["A"].device)
+            Mi = torch.empty((self.N, self.m, self.m), dtype=torch.float64, device=d["A"].device)
+            rc = _lib.lib().zm_mpc_setup_f64(d["A"].data_ptr(), d["B"].data_ptr(), d["Q"].data_ptr(), d["R"].data_ptr(),
+                                             d["Qf"].data_ptr(), float(rho), self.N, self.n, self.m, K.data_ptr(),
+                                             Mi.data_ptr(), ctypes.c_void_p(arr.stream_ptr(K)))
+            _lib.check(rc, "lqrMpc setup")
+            self._tables[rho] = (K, Mi)
+        return self._dev, self._tables[rho]
+
+    def solve(self, x0, **kwargs):
+        """
+        Solve the MPC step at state x0 (reference mpcUtils.py:61-81)
+
+        Arguments
+        ---------
+            x0 : Initial state (n,) -- or (..., n): a batch of independent instances
+            **kwargs : solver options, named as the OSQP options the reference forwards through cvxpy
+                (demos/lqrMpc.py:32): eps_abs, eps_rel (default 1e-5, cvxpy's OSQP default), max_iter (default 10000),
+                rho, eps_prim_inf (default 1e-4); `solver` may be None or "OSQP" (the build has one solver);
+                eps_dual_inf / verbose / warm_start / polish are accepted and ignored.
+
+        Returns
+        -------
+            u : Optimal control at current time step (…, m)
+            traj : Trajectory tuple (xTraj (…, N+1, n), uTraj (…, N, m))
+            status : problem status, one of [optimal, infeasible, user_limit] (a list of them for a batch)
+        """
+        solver = kwargs.pop("solver", None)
+        if solver not in (None, "OSQP"):
+            raise ValueError(f"solver {solver!r} is not available in zopt_amd (ADMM only; pass solver='OSQP' or None)")
+        eps_abs = float(kwargs.pop("eps_abs", 1e-5))
+        eps_rel = float(kwargs.pop("eps_rel", 1e-5))
+        max_iter = int(kwargs.pop("max_iter", 10000))
+        rho = float(kwargs.pop("rho", self.rho))
+        eps_pinf = float(kwargs.pop("eps_prim_inf", 1e-4))
+        for k in ("eps_dual_inf", "verbose", "warm_start", "warm_starting", "polish", "polishing"):
+            kwargs.pop(k, None)
+        if kwargs:
+            raise TypeError(f"unknown solver options {sorted(kwargs)}")
+        shp = tuple(x0.shape) if hasattr(x0, "shape") else tuple(np.shape(x0))
+        if len(shp) < 1 or shp[-1] != self.n:
+            raise ValueError(f"x0 has shape {shp}, expected (..., {self.n})")
+        lead = shp[:-1]
+        d, (K, Mi) = self._device_problem(rho)
+        dx0 = arr.to_device(x0, torch.float64).reshape(-1, self.n).contiguous()
+        Bn = dx0.shape[0]
+        dev = dx0.device
+        N, n, m = self.N, self.n, self.m
+        ws = torch.empty(4 * Bn * N * (n + m), dtype=torch.float64, device=dev)
+        xT = torch.empty((Bn, N + 1, n), dtype=torch.float64, device=dev)
+        uT = torch.empty((Bn, N, m), dtype=torch.float64, device=dev)
+        st = torch.empty(Bn, dtype=torch.int32, device=dev)
+        its = torch.empty(Bn, dtype=torch.int32, device=dev)
+        res = torch.empty((Bn, 2), dtype=torch.float64, device=dev)
+        rc = _lib.lib().zm_mpc_solve_f64(d["A"].data_ptr(), d["B"].data_ptr(), K.data_ptr(), Mi.data_ptr(),
+                                         d["x_lb"].data_ptr(), d["x_ub"].data_ptr(), d["u_lb"].data_ptr(),
+                                         d["u_ub"].data_ptr(), dx0.data_ptr(), rho, eps_abs, eps_rel, eps_pinf, max_iter,
+                                         ws.data_ptr(), xT.data_ptr(), uT.data_ptr(), st.data_ptr(), its.data_ptr(),
+                                         res.data_ptr(), Bn, N, n, m, ctypes.c_void_p(arr.stream_ptr(dx0)))
+        _lib.check(rc, "lqrMpc.solve")
+        self.last_iterations = its.reshape(lead).cpu().numpy()
+        self.last_residuals = res.reshape(lead + (2,)).cpu().numpy()
+        codes = st.cpu().numpy().reshape(lead)
+        xo = arr.result_like(xT.reshape(lead + (N + 1, n)), x0)
+        uo = arr.result_like(uT.reshape(lead + (N, m)), x0)
+        if len(lead) == 0:
+            status = _STATUS[int(codes)]
+        else:
+            status = np.vectorize(_STATUS.get, otypes=[object])(codes)
+        return uo[..., 0, :], Trajectory(xo, uo), status
