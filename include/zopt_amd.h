@@ -144,6 +144,27 @@ int zm_ilqr_backward_ex_f64(const double* f_x, const double* f_u, const double* 
                             const double* vf_xx, const int32_t* active, int shared_hessian, double* l, double* L,
                             int64_t batch, int T, int n, int m, void* stream);
 
+/* Batched DDP backward pass: zm_ilqr_backward_ex_f64 plus the second-order dynamics terms.
+ * Replaces: zopt/ilqrUtils.py:184-214 riccatiStep_ddp / backwardPass_ddp and :237-251 conditionQuadraticDynamics:
+ *     vf_.. = einsum('i,ijk', v_x, f_..);  [[vf_xx, vf_ux^T],[vf_ux, vf_uu]] <- ensurePositiveDefinite(.)  per step,
+ *     Q_xx += vf_xx, Q_uu += vf_uu, Q_ux += vf_ux, then the iLQR step.
+ * in : as zm_ilqr_backward_ex_f64, plus QuadraticDynamics (pytrees.py:165-177)
+ *      f_xx (batch,T,n,n,n)  f_ux (batch,T,n,m,n)  f_uu (batch,T,n,m,m)     [f_..[i,j,k] = d2 f_i / d._j d._k]
+ * out: l (batch,T,m)  L (batch,T,m,n)
+ */
+int zm_ddp_backward_f64(const double* f_x, const double* f_u, const double* f_xx, const double* f_ux, const double* f_uu,
+                        const double* c_x, const double* c_u, const double* c_xx, const double* c_ux, const double* c_uu,
+                        const double* vf_x, const double* vf_xx, const int32_t* active, int shared_hessian, double* l,
+                        double* L, int64_t batch, int T, int n, int m, void* stream);
+
+/* Second-order expansion of a registered model along a trajectory (forward-mode hyper-dual numbers).
+ * Replaces: zopt/pytrees.py:180-194 QuadraticDynamics.from_function / from_trajectory (jax.hessian of dynFun):
+ * in : xTraj (batch,T+1,n)  uTraj (batch,T,m)  active or NULL
+ * out: f_xx (batch,T,n,n,n)  f_ux (batch,T,n,m,n)  f_uu (batch,T,n,m,m)
+ */
+int zm_quadratic_dynamics_f64(const zm_model_t* model, const double* xTraj, const double* uTraj, const int32_t* active,
+                              double* f_xx, double* f_ux, double* f_uu, int64_t batch, int T, void* stream);
+
 /* Batched projection onto the positive definite cone: A <- V max(w, eps) V^T with (w, V) = eigh((A + A^T)/2).
  * Replaces: zopt/ilqrUtils.py:217-219 ensurePositiveDefinite (jnp.linalg.eigh symmetrises its input) and its users
  *           :254-257 conditionValueFunction (k = n).       in/out: A (count,k,k) in place, k <= 16.

@@ -485,3 +485,85 @@ def iterativeLqr(dynFun, Q, R, Qf, x0, uGuess, maxIter=100, tol=1e-3, return_ite
         it += 1
     out = (traj, policy.L, J, converged)
     return out + (it,) if return_iters else out
+
+
+# ----------------------------------------------------------------------------------------
+# A9 (second order) QuadraticDynamics.from_trajectory            reference pytrees.py:180-194
+# ----------------------------------------------------------------------------------------
+def quad_euler_step_torch(dt):
+    """torch (CPU, fp64) restatement of x+ = x + dt*inertialDynamics(x,u) (quadcopter.py:23-144), used only to obtain exact
+    second derivatives by autograd -- the role jax.hessian plays in QuadraticDynamics.from_function (pytrees.py:180-186)."""
+    import torch
+
+    def f(x, u):
+        uvw, pqr = x[0:3], x[3:6]
+        phi, theta, psi = x[6], x[7], x[8]
+        cphi, sphi = torch.cos(phi), torch.sin(phi)
+        cth, sth, tth = torch.cos(theta), torch.sin(theta), torch.tan(theta)
+        cpsi, spsi = torch.cos(psi), torch.sin(psi)
+        R = torch.stack([
+            torch.stack([cth * cpsi, sphi * sth * cpsi - cphi * spsi, cphi * sth * cpsi - sphi * spsi]),
+            torch.stack([cth * spsi, sphi * sth * spsi + cphi * cpsi, cphi * sth * spsi - sphi * cpsi]),
+            torch.stack([-sth, sphi * cth, cphi * cth])])
+        one, zero = torch.ones_like(phi), torch.zeros_like(phi)
+        E = torch.stack([torch.stack([one, sphi * tth, cphi * tth]), torch.stack([zero, cphi, -sphi]),
+                         torch.stack([zero, sphi / cth, cphi / cth])])
+        flin = torch.tensor(QUAD_FORCE_LIN, dtype=x.dtype)
+        fquad = torch.tensor(QUAD_FORCE_QUAD, dtype=x.dtype)
+        mlin = torch.tensor(QUAD_MOMENT_LIN, dtype=x.dtype)
+        force_aero = flin * uvw + fquad * uvw ** 2
+        d2xyz = torch.stack([-sth, sphi * cth, cphi * cth])
+        force_total = QUAD_MASS * torch.stack([zero, zero, -u[0]]) + force_aero + QUAD_MASS * QUAD_G * d2xyz
+        uvwDot = (1 / QUAD_MASS) * (-torch.linalg.cross(pqr, uvw) + force_total)
+        pqrDot = u[1:4] + mlin * pqr
+        eul = E @ pqr
+        xyzDot = R @ uvw
+        xd = torch.cat([uvwDot, pqrDot, eul, xyzDot])
+        return x + dt * xd
+    return f
+
+
+def quadratic_dynamics_from_trajectory(f_torch, traj: Trajectory) -> QuadraticDynamics:
+    """QuadraticDynamics.from_trajectory (pytrees.py:188-194) by torch autograd on CPU:
+    f_xx[i,j,k] = d2f_i/dx_j dx_k, f_ux[i,j,k] = d2f_i/du_j dx_k, f_uu[i,j,k] = d2f_i/du_j du_k."""
+    import torch
+    from torch.func import hessian, jacfwd
+    xT, uT = (torch.as_tensor(np.asarray(t), dtype=torch.float64) for t in traj)
+    fs, fx, fu, fxx, fux, fuu = [], [], [], [], [], []
+    for k in range(uT.shape[0]):
+        x, u = xT[k], uT[k]
+        fs.append(f_torch(x, u))
+        jx, ju = jacfwd(f_torch, argnums=(0, 1))(x, u)
+        (hxx, hxu), (hux, huu) = hessian(f_torch, argnums=(0, 1))(x, u)
+        fx.append(jx); fu.append(ju); fxx.append(hxx); fux.append(hux); fuu.append(huu)
+    st = lambda L: torch.stack(L).numpy()
+    return QuadraticDynamics(st(fs), st(fx), st(fu), st(fxx), st(fux), st(fuu))
+
+
+# ----------------------------------------------------------------------------------------
+# A8 (DDP) differentialDynamicProgramming                 reference ilqrUtils.py:330-397
+# ----------------------------------------------------------------------------------------
+def differentialDynamicProgramming(dynFun, f_torch, Q, R, Qf, x0, uGuess, maxIter=100, tol=1e-3, return_iters=False):
+    """DDP loop of ilqrUtils.py:360-397: as iterativeLqr with QuadraticDynamics (:365) and backwardPass_ddp (:373).
+    `dynFun` (NumPy) rolls out, `f_torch` (the same map in torch) supplies the first and second derivatives."""
+    Q, R, Qf = (np.asarray(t, dtype=np.float64) for t in (Q, R, Qf))
+    x0 = np.asarray(x0, dtype=np.float64)
+    uGuess = np.asarray(uGuess, dtype=np.float64)
+    n = x0.shape[0]
+    N, m = uGuess.shape
+    runningCost, terminalCost = quadratic_costs(Q, R, Qf)
+    policy = AffinePolicy(uGuess, np.zeros((N, m, n)))
+    traj = trajectoryRollout(x0, dynFun, policy, Trajectory(np.zeros((N + 1, n)), np.zeros((N, m))))
+    J = trajectoryCost(runningCost, terminalCost, traj)
+    converged, it = False, 0
+    while (not converged) and it < maxIter:
+        dyn = quadratic_dynamics_from_trajectory(f_torch, traj)
+        cost = conditionQuadraticCost(quadratic_cost_from_trajectory(Q, R, traj))
+        Vf = conditionValueFunction(terminal_value_function(Qf, traj.xTraj[-1]))
+        policy = backwardPass_ddp(dyn, cost, Vf)
+        traj_new, J_new = forwardPass2(x0, dynFun, runningCost, terminalCost, policy, traj)
+        converged = bool(abs(J - J_new) <= tol)
+        traj, J = traj_new, J_new
+        it += 1
+    out = (traj, policy.L, J, converged)
+    return out + (it,) if return_iters else out

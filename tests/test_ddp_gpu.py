@@ -1,0 +1,118 @@
+"""GPU parity tests for K4 ddp_backward, the second-order lineariser and the DDP driver
+(reference ilqrUtils.py:184-214, 237-251, 330-397; pytrees.py:180-194)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import zopt_oracle as zo
+from tests import problems
+
+pytestmark = pytest.mark.gpu
+KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
+
+
+def _rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import torch
+    assert torch.cuda.is_available()
+    from zopt_amd import _lib, ilqrUtils, models, pytrees
+    return ilqrUtils, models, pytrees, _lib
+
+
+def test_kat_riccati_step_ddp(mods):
+    """reference tests/test_ilqrUtils.py:110-135 as a 1-step DDP backward pass with zero second derivatives:
+    v_xx = 1.5 I, L = -0.5 I at rel 1e-3 (the PD clamp adds 1e-3 I to Q_xx, Q_uu)."""
+    ilqr, _, pt, _ = mods
+    I2 = np.eye(2)
+    z = np.zeros((1, 2, 2, 2))
+    dyn = pt.QuadraticDynamics(np.zeros((1, 2)), I2[None], I2[None], z, z, z)
+    cost = pt.QuadraticCostFunction(np.zeros(1), np.zeros((1, 2)), np.zeros((1, 2)), I2[None], np.zeros((1, 2, 2)), I2[None])
+    pol = ilqr.backwardPass_ddp(dyn, cost, pt.QuadraticValueFunction(0.0, np.zeros(2), I2))
+    assert pol.l[0] == pytest.approx(np.array(KATS["A4_riccatiStep_ddp"]["l"]))
+    assert pol.L[0] == pytest.approx(np.array(KATS["A4_riccatiStep_ddp"]["L"]), rel=1e-3)
+    # exact value with the clamp: Q_uu = (1 + 1 + 1e-3) I, Q_ux = I  ->  L = -1/2.001 I
+    assert pol.L[0] == pytest.approx(-np.eye(2) / 2.001, rel=1e-12)
+
+
+@pytest.mark.parametrize("n,m,T,batch", [(12, 4, 20, 4), (2, 2, 3, 3), (4, 1, 7, 2), (8, 4, 5, 2), (5, 3, 4, 2), (12, 4, 1, 2)])
+def test_backwardPass_ddp_parity(mods, n, m, T, batch):
+    ilqr = mods[0]
+    dyn, cost, Vf = problems.random_ilqr_model(batch, T, n, m, seed=7 * n + m + T)
+    rng = np.random.default_rng(n + m)
+    sym = lambda X: 0.5 * (X + np.swapaxes(X, -1, -2))
+    f_xx = 0.2 * sym(rng.standard_normal((batch, T, n, n, n)))
+    f_ux = 0.2 * rng.standard_normal((batch, T, n, m, n))
+    f_uu = 0.2 * sym(rng.standard_normal((batch, T, n, m, m)))
+    pol = ilqr.backwardPass_ddp(dyn + (f_xx, f_ux, f_uu), cost, Vf)
+    ref = zo.backwardPass_ddp(zo.QuadraticDynamics(*dyn, f_xx, f_ux, f_uu), zo.QuadraticCostFunction(*cost),
+                              zo.QuadraticValueFunction(*Vf))
+    assert _rel(pol.L, ref.L) <= 1e-9 and _rel(pol.l, ref.l) <= 1e-9
+
+
+def test_quadratic_dynamics_quadcopter(mods):
+    """Hyper-dual second derivatives of the device model vs torch autograd of the oracle's restatement (pytrees.py:180-194)."""
+    import ctypes
+    import torch
+    _, models, _, _lib = mods
+    rng = np.random.default_rng(9)
+    b, N = 2, 5
+    xT = 0.4 * rng.standard_normal((b, N + 1, 12))
+    uT = np.array([9.807, 0, 0, 0]) + 0.5 * rng.standard_normal((b, N, 4))
+    dx, du = torch.as_tensor(xT, device="cuda"), torch.as_tensor(uT, device="cuda")
+    t = lambda *s: torch.full(s, float("nan"), dtype=torch.float64, device="cuda")
+    f_xx, f_ux, f_uu = t(b, N, 12, 12, 12), t(b, N, 12, 4, 12), t(b, N, 12, 4, 4)
+    md = models.QuadcopterEuler(0.1).c_struct()
+    rc = _lib.lib().zm_quadratic_dynamics_f64(ctypes.addressof(md), dx.data_ptr(), du.data_ptr(), None, f_xx.data_ptr(),
+                                              f_ux.data_ptr(), f_uu.data_ptr(), b, N, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    ft = zo.quad_euler_step_torch(0.1)
+    for i in range(b):
+        ref = zo.quadratic_dynamics_from_trajectory(ft, zo.Trajectory(xT[i], uT[i]))
+        assert np.max(np.abs(f_xx[i].cpu().numpy() - ref.f_xx)) <= 1e-12
+        assert np.max(np.abs(f_ux[i].cpu().numpy() - ref.f_ux)) <= 1e-12
+        assert np.max(np.abs(f_uu[i].cpu().numpy() - ref.f_uu)) <= 1e-12
+    assert np.max(np.abs(f_xx.cpu().numpy())) > 1e-3      # the model really has curvature
+
+
+def test_kat_ddp_driver(mods):
+    """reference tests/test_ilqrUtils.py:184-196: A=B=Q=R=I, N=3, x0=(2,1) -> converged (LQ: second derivatives vanish,
+    only the 1e-3 clamp of the zero vf_zz differs from iLQR)."""
+    ilqr, models, _, _ = mods
+    I = np.eye(2)
+    cost = models.QuadraticCost(I, I, I)
+    x0 = np.array([2.0, 1.0])
+    traj, L, J, converged = ilqr.differentialDynamicProgramming(models.LinearModel(I, I), cost.runningCost, cost.terminalCost,
+                                                               x0, np.zeros((3, 2)))
+    assert converged is True
+    import torch
+    ft = lambda x, u: x + u
+    rt, rL, rJ, rc = zo.differentialDynamicProgramming(lambda x, u: x + u, ft, I, I, I, x0, np.zeros((3, 2)))
+    assert rc and _rel(traj.uTraj, rt.uTraj) <= 1e-9 and _rel(L, rL) <= 1e-9 and J == pytest.approx(rJ, rel=1e-10)
+
+
+def test_ddp_quadcopter_demo_problem(mods):
+    """demos/differentialDynamicProgramming.py:22-39: quadcopter, N=100 (here 40 to bound the oracle's CPU time), Q=I,
+    R=0.2 I, terminal 10 x'Qx, x0[9:12]=(0,5,0), uGuess=uTrim, against the CPU oracle loop."""
+    ilqr, models, _, _ = mods
+    N = 40
+    Q, R = np.eye(12), 0.2 * np.eye(4)
+    Qf = 10 * Q
+    cost = models.QuadraticCost(Q, R, Qf)
+    x0 = np.zeros((2, 12))
+    x0[0, 9:12] = [0, 5, 0]
+    x0[1, 9:12] = [1, -2, 3]
+    ug = np.tile(models.QuadcopterEuler.uTrim, (2, N, 1))
+    traj, L, J, converged = ilqr.differentialDynamicProgramming(models.QuadcopterEuler(0.1), cost, cost, x0, ug)
+    fn, ft = zo.quad_euler_step(0.1), zo.quad_euler_step_torch(0.1)
+    for i in range(2):
+        rt, rL, rJ, rc = zo.differentialDynamicProgramming(fn, ft, Q, R, Qf, x0[i], ug[i])
+        assert bool(converged[i]) == rc
+        assert J[i] == pytest.approx(rJ, rel=1e-7)
+        assert _rel(traj.xTraj[i], rt.xTraj) <= 1e-6 and _rel(traj.uTraj[i], rt.uTraj) <= 1e-6 and _rel(L[i], rL) <= 1e-5

@@ -49,6 +49,11 @@ SYMBOLS = {
     #  batch, N, n, m, stream)
     "zm_mpc_solve_f64": (ctypes.c_int, [_c_dp] * 9 + [ctypes.c_double] * 4 + [ctypes.c_int] + [_c_dp] * 6 +
                          [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    # (f_x, f_u, f_xx, f_ux, f_uu, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, active, shared_hessian, l, L, batch, T, n, m, stream)
+    "zm_ddp_backward_f64": (ctypes.c_int, [_c_dp] * 13 + [ctypes.c_int] + [_c_dp] * 2 +
+                            [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    # (model*, xTraj, uTraj, active, f_xx, f_ux, f_uu, batch, T, stream)
+    "zm_quadratic_dynamics_f64": (ctypes.c_int, [_c_dp] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "zm_psd_project_f64": (ctypes.c_int, [_c_dp, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
     "zm_condition_cost_f64": (ctypes.c_int, [_c_dp] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                                           ctypes.c_void_p]),

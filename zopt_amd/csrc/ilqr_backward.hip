@@ -19,6 +19,14 @@
 // 2*KS + 2 MFMAs per step.  Inputs are read once with 8-byte loads straight into their register layouts, two steps
 // ahead (register double buffer).  Shapes: n <= 12, m <= 4.
 //
+// MODE 2 = K4 ddp_backward: zopt/ilqrUtils.py:184-214 (riccatiStep_ddp / backwardPass_ddp) = MODE 0 plus, per step,
+//     vf_zz = [[vf_xx, vf_ux^T],[vf_ux, vf_uu]],  vf_.. = einsum('i,ijk', v_x, f_..)                  (:240-247)
+//     vf_zz <- ensurePositiveDefinite(vf_zz)   (eigenvalue clamp 1e-3, INSIDE the sequential sweep)    (:248)
+//     Q_xx += vf_xx,  Q_uu += vf_uu,  Q_ux += vf_ux                                                    (:196-198)
+// The contraction reads f_xx (n,n,n), f_ux (n,m,n), f_uu (n,m,m) of the step straight from HBM (n terms per tile
+// element), the compact (n+m) x (n+m) matrix goes through LDS into the wave-level Jacobi projection of jacobi16.h and
+// comes back as an accumulator init of G.
+//
 // MODE 1 = K2 lqr_backward_affine: the same sweep for zopt/lqrUtils.py:207-262 (bilinearAffineLqr), i.e. with
 //     f_x,f_u <- A,B   c_xx,c_ux,c_uu <- Q,H,R   c_x,c_u <- q,r   and the affine-dynamics offset d:
 //     Su  = r + B^T (v + V^T d)      Suu = R + B^T V B      Sux = H + B^T V A                       (:244-246)
@@ -27,6 +35,7 @@
 // (v0 / q0 never influence L or l and are not carried.)  V d is a row reduction of the V registers (4 xor-shuffles per
 // K-step), V^T d a column reduction (2 shuffles) re-laid out through LDS; both are kept apart so that a
 // nonsymmetric V is treated exactly as the reference does.
+#include "jacobi16.h"
 #include "tile16_f64.h"
 #include "zm_common.h"
 
@@ -50,6 +59,9 @@ struct IlqrAddr {
     const double* pcv;
     const double* pdc;   // MODE 1
     const double* pdr0;  // MODE 1: K-step s adds (rowok ? 4 s : 0)
+    const double* pz[4]; // MODE 2: element (4r+g, c) of the stacked second-derivative tensor slice i = 0; +i*sz[r]
+    int sz[4], stz[4];   // MODE 2: stride over i, stride over the time step
+    int zc[4];           // MODE 2: compact LDS index a*PLD+b of tile element (4r+g, c), or -1
     double* pOut;        // L_k[g][c] (c < n) or l_k[g] (c == NP)
     int dF, dC, sF, sC, sCu, scv, sOut, sd;
     bool rowok[KS], vF[KS], vC[KS], vCu, vcv, vOut, vL, cA;
@@ -102,8 +114,45 @@ __device__ __forceinline__ void ilqr_lds_sync() {
 template <int KS, int MODE, bool PREFETCH>
 __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], IlqrStepRegs<KS>& d, IlqrAddr<KS>& a,
                                           double* sm, const int g, const int c, const int ob0, const int ob1,
-                                          const int ob2, const int ob3, const int oqa) {
+                                          const int ob2, const int ob3, const int oqa, double* jA, double* jV,
+                                          double* jcs, int* jpq, const int n, const int m) {
     constexpr int NP = 4 * KS;
+    // MODE 2: vf_zz = sum_i v_x[i] * d2f_i/dz2, PD-projected, as extra accumulator init
+    d4 pz = zero4();
+    if constexpr (MODE == 2) {
+        const int lane = g * 16 + c;
+        double z[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = 0; i < n; ++i) {
+            const double vxi = sm[80 + i];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[r] = __builtin_fma(vxi, a.pz[r][(long)i * a.sz[r]], z[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a.pz[r] -= a.stz[r];
+            if (a.zc[r] >= 0) jA[a.zc[r]] = z[r];
+        }
+        ilqr_lds_sync();
+        // symmetrise (jnp.linalg.eigh does) -- in place through registers
+        const int k = n + m;
+        double sy[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = lane + 64 * r;
+            const int i = e / k, j = e % k;
+            sy[r] = (e < k * k) ? 0.5 * (jA[i * PLD + j] + jA[j * PLD + i]) : 0.0;
+        }
+        ilqr_lds_sync();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = lane + 64 * r;
+            if (e < k * k) jA[(e / k) * PLD + (e % k)] = sy[r];
+        }
+        ilqr_lds_sync();
+        psd_project_lds(jA, jV, jcs, jpq, k, 1e-3, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pz[r] = (a.zc[r] >= 0) ? jA[a.zc[r]] : 0.0;
+    }
     // Y = v_xx^T F
     d4 y = zero4();
 #pragma unroll
@@ -111,8 +160,8 @@ __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], 
     // G = Y^T F + C0
     d4 gacc = zero4();
 #pragma unroll
-    for (int s = 0; s < KS; ++s) gacc[s] = d.C[s];
-    gacc[KS] = d.Cu;
+    for (int s = 0; s < KS; ++s) gacc[s] = d.C[s] + pz[s];
+    gacc[KS] = d.Cu + pz[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) gacc = mfma(y[s], d.F[s], gacc);
     // q[c] = cv[c] + sum_k F[k][c] w[k]   (partial over this lane's rows, then over the 4 lane groups);
@@ -210,7 +259,8 @@ __global__ __launch_bounds__(64) void ilqr_backward_t16_f64(
     const double* __restrict__ f_x, const double* __restrict__ f_u, const double* __restrict__ c_x,
     const double* __restrict__ c_u, const double* __restrict__ c_xx, const double* __restrict__ c_ux,
     const double* __restrict__ c_uu, const double* __restrict__ vf_x, const double* __restrict__ vf_xx,
-    const double* __restrict__ dvec, const long svx, const long svxx, const int* __restrict__ active,
+    const double* __restrict__ dvec, const double* __restrict__ f_xx, const double* __restrict__ f_ux,
+    const double* __restrict__ f_uu, const long svx, const long svxx, const int* __restrict__ active,
     const int shared_h, double* __restrict__ lout, double* __restrict__ Lout, const int T, const int n, const int m) {
     constexpr int NP = 4 * KS;
     const int lane = threadIdx.x;
@@ -218,6 +268,8 @@ __global__ __launch_bounds__(64) void ilqr_backward_t16_f64(
     if (active && active[traj] == 0) return;  // whole wave leaves: this trajectory keeps its previous policy
     const int g = lane >> 4, c = lane & 15;
     __shared__ double sm[ILQR_LDS_DOUBLES];
+    __shared__ double jA[MODE == 2 ? PK * PLD : 1], jV[MODE == 2 ? PK * PLD : 1], jcs[PK];
+    __shared__ int jpq[PK];
 
     IlqrAddr<KS> a;
     const int nn = n * n, nm = n * m, mm = m * m;
@@ -263,6 +315,32 @@ __global__ __launch_bounds__(64) void ilqr_backward_t16_f64(
         a.pdr0 = row0 ? (dt_ + g) : dt_;
         a.sd = n;
     }
+    if constexpr (MODE == 2) {
+        const long nnn = (long)nn * n, nmn = (long)nm * n, nmm = (long)nm * m;
+        const double* fxxt = f_xx + last * nnn;
+        const double* fuxt = f_ux + last * nmn;
+        const double* fuut = f_uu + last * nmm;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * r + g;
+            const bool rx = row < n, ru = (row >= NP) && (row < NP + m);
+            // compact index: states 0..n-1, controls n..n+m-1
+            const int ca = rx ? row : (ru ? n + (row - NP) : -1);
+            const int cb = cA ? c : (cB ? n + (c - NP) : -1);
+            a.zc[r] = (ca >= 0 && cb >= 0) ? ca * PLD + cb : -1;
+            if (rx && cA) {            // f_xx[i][row][c]
+                a.pz[r] = fxxt + row * n + c;  a.sz[r] = nn;  a.stz[r] = (int)nnn;
+            } else if (rx && cB) {     // (vf_ux)^T: f_ux[i][c-NP][row]
+                a.pz[r] = fuxt + (c - NP) * n + row;  a.sz[r] = nm;  a.stz[r] = (int)nmn;
+            } else if (ru && cA) {     // f_ux[i][row-NP][c]
+                a.pz[r] = fuxt + (row - NP) * n + c;  a.sz[r] = nm;  a.stz[r] = (int)nmn;
+            } else if (ru && cB) {     // f_uu[i][row-NP][c-NP]
+                a.pz[r] = fuut + (row - NP) * m + (c - NP);  a.sz[r] = mm;  a.stz[r] = (int)nmm;
+            } else {                   // padding: finite don't-care data, dropped (zc = -1)
+                a.pz[r] = fxxt;  a.sz[r] = 0;  a.stz[r] = (int)nnn;
+            }
+        }
+    }
     a.vL = (g < m) && cA;
     const bool vl = (g < m) && (c == NP);
     a.vOut = a.vL || vl;
@@ -295,45 +373,51 @@ __global__ __launch_bounds__(64) void ilqr_backward_t16_f64(
         }
     }
 
+    if (g == 0) sm[80 + c] = cA ? (vf_x + traj * svx)[c] : 0.0;  // v_x (column-indexed), read by MODE 2's contraction
+    ilqr_lds_sync();
     IlqrStepRegs<KS> d0, d1;
     ilqr_load_step<KS, MODE>(d0, a);
     if (T >= 2) ilqr_load_step<KS, MODE>(d1, a);
     int k = T - 1;
     while (k >= 3) {
-        ilqr_step<KS, MODE, true>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
-        ilqr_step<KS, MODE, true>(Vxx, vxr, d1, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
+        ilqr_step<KS, MODE, true>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, jA, jV, jcs, jpq, n, m);
+        ilqr_step<KS, MODE, true>(Vxx, vxr, d1, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, jA, jV, jcs, jpq, n, m);
         k -= 2;
     }
     if (k == 2) {
-        ilqr_step<KS, MODE, true>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
-        ilqr_step<KS, MODE, false>(Vxx, vxr, d1, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
-        ilqr_step<KS, MODE, false>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
+        ilqr_step<KS, MODE, true>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, jA, jV, jcs, jpq, n, m);
+        ilqr_step<KS, MODE, false>(Vxx, vxr, d1, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, jA, jV, jcs, jpq, n, m);
+        ilqr_step<KS, MODE, false>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, jA, jV, jcs, jpq, n, m);
     } else if (k == 1) {
-        ilqr_step<KS, MODE, false>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
-        ilqr_step<KS, MODE, false>(Vxx, vxr, d1, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
+        ilqr_step<KS, MODE, false>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, jA, jV, jcs, jpq, n, m);
+        ilqr_step<KS, MODE, false>(Vxx, vxr, d1, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, jA, jV, jcs, jpq, n, m);
     } else {
-        ilqr_step<KS, MODE, false>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa);
+        ilqr_step<KS, MODE, false>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, jA, jV, jcs, jpq, n, m);
     }
 }
 
 }  // namespace zm
 
 namespace zm {
+struct DdpTensors {
+    const double *f_xx, *f_ux, *f_uu;
+};
+
 template <int MODE>
 static int launch_ilqr(const double* f_x, const double* f_u, const double* c_x, const double* c_u, const double* c_xx,
                        const double* c_ux, const double* c_uu, const double* vf_x, const double* vf_xx, const double* d,
                        long svx, long svxx, const int* act, int sh, double* l, double* L, int64_t batch, int T, int n, int m,
-                       hipStream_t st) {
+                       hipStream_t st, DdpTensors z = DdpTensors{nullptr, nullptr, nullptr}) {
     const dim3 grid((unsigned)batch), block(64);
     if (n <= 4)
         hipLaunchKernelGGL((ilqr_backward_t16_f64<1, MODE>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
-                           vf_xx, d, svx, svxx, act, sh, l, L, T, n, m);
+                           vf_xx, d, z.f_xx, z.f_ux, z.f_uu, svx, svxx, act, sh, l, L, T, n, m);
     else if (n <= 8)
         hipLaunchKernelGGL((ilqr_backward_t16_f64<2, MODE>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
-                           vf_xx, d, svx, svxx, act, sh, l, L, T, n, m);
+                           vf_xx, d, z.f_xx, z.f_ux, z.f_uu, svx, svxx, act, sh, l, L, T, n, m);
     else
         hipLaunchKernelGGL((ilqr_backward_t16_f64<3, MODE>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
-                           vf_xx, d, svx, svxx, act, sh, l, L, T, n, m);
+                           vf_xx, d, z.f_xx, z.f_ux, z.f_uu, svx, svxx, act, sh, l, L, T, n, m);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }
@@ -382,4 +466,20 @@ extern "C" int zm_lqr_backward_affine_f64(const double* A, const double* B, cons
     const double* vf_x = q + (int64_t)(T - 1) * n;
     return zm::launch_ilqr<1>(A, B, q, r, Q, H, R, vf_x, vf_xx, d, (long)T * n, (long)T * n * n, nullptr, 0, l, L, batch, T,
                               n, m, (hipStream_t)stream);
+}
+
+extern "C" int zm_ddp_backward_f64(const double* f_x, const double* f_u, const double* f_xx, const double* f_ux,
+                                   const double* f_uu, const double* c_x, const double* c_u, const double* c_xx,
+                                   const double* c_ux, const double* c_uu, const double* vf_x, const double* vf_xx,
+                                   const int32_t* active, int shared_hessian, double* l, double* L, int64_t batch, int T,
+                                   int n, int m, void* stream) {
+    if (!f_x || !f_u || !f_xx || !f_ux || !f_uu || !c_x || !c_u || !c_xx || !c_ux || !c_uu || !vf_x || !vf_xx || !l || !L)
+        return zm::set_error(ZM_EINVAL, "zm_ddp_backward_f64: null pointer");
+    const int rc = zm_check_sweep_args("zm_ddp_backward_f64", batch, T, n, m);
+    if (rc) return rc;
+    if ((int64_t)n * n * n >= (int64_t)1 << 31) return zm::set_error(ZM_EUNSUPPORTED, "zm_ddp_backward_f64: n too large");
+    if (batch == 0) return ZM_OK;
+    return zm::launch_ilqr<2>(f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, (long)n, (long)n * n,
+                              (const int*)active, shared_hessian ? 1 : 0, l, L, batch, T, n, m, (hipStream_t)stream,
+                              zm::DdpTensors{f_xx, f_ux, f_uu});
 }

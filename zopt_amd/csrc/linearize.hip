@@ -55,6 +55,56 @@ __global__ __launch_bounds__(64) void linearize_dynamics_kernel(const zm_model_t
     }
 }
 
+// quadratic_dynamics: one wave per (trajectory, step) point; the (n+m)(n+m+1)/2 <= 136 unordered derivative pairs (a, b) are
+// spread over the lanes (<= 3 per lane), each evaluated once on hyper-dual numbers seeded e_a, e_b.
+__global__ __launch_bounds__(64) void quadratic_dynamics_kernel(const zm_model_t md, const double* __restrict__ xTraj,
+                                                                const double* __restrict__ uTraj,
+                                                                const int* __restrict__ active, double* __restrict__ f_xx,
+                                                                double* __restrict__ f_ux, double* __restrict__ f_uu,
+                                                                const long batch, const int T) {
+    const long pt = blockIdx.x;
+    const long traj = pt / T;
+    const int k = (int)(pt - traj * T);
+    if (active && active[traj] == 0) return;
+    const int n = md.n, m = md.m, K = n + m;
+    const int npairs = K * (K + 1) / 2;
+    const double* xk = xTraj + (traj * (T + 1) + k) * n;
+    const double* uk = uTraj + pt * m;
+    double* oxx = f_xx + pt * n * n * n;
+    double* oux = f_ux + pt * n * m * n;
+    double* ouu = f_uu + pt * n * m * m;
+    for (int p = threadIdx.x; p < npairs; p += 64) {
+        int a = 0, rem = p;
+        while (rem >= K - a) {  // row a of the upper triangle holds K - a pairs (a, a..K-1)
+            rem -= K - a;
+            ++a;
+        }
+        const int b = a + rem;
+        Hyper x[MAXN], u[MAXM], xn[MAXN];
+#pragma unroll
+        for (int i = 0; i < MAXN; ++i) x[i] = Hyper{(i < n) ? xk[i] : 0.0, (i == a) ? 1.0 : 0.0, (i == b) ? 1.0 : 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < MAXM; ++i)
+            u[i] = Hyper{(i < m) ? uk[i] : 0.0, (n + i == a) ? 1.0 : 0.0, (n + i == b) ? 1.0 : 0.0, 0.0};
+        model_step<Hyper>(md, x, u, xn);
+#pragma unroll
+        for (int i = 0; i < MAXN; ++i) {
+            if (i < n) {
+                const double h = xn[i].d12;  // d2 f_i / dz_a dz_b,  a <= b
+                if (b < n) {                 // both states: f_xx[i][a][b] = f_xx[i][b][a]
+                    oxx[(i * n + a) * n + b] = h;
+                    oxx[(i * n + b) * n + a] = h;
+                } else if (a < n) {          // a state, b control: f_ux[i][b-n][a]
+                    oux[(i * m + (b - n)) * n + a] = h;
+                } else {                     // both controls
+                    ouu[(i * m + (a - n)) * m + (b - n)] = h;
+                    ouu[(i * m + (b - n)) * m + (a - n)] = h;
+                }
+            }
+        }
+    }
+}
+
 // one thread per (trajectory, step) point plus one per trajectory for the terminal expansion
 __global__ __launch_bounds__(256) void quadratize_cost_kernel(const zm_quadcost_t cs, const int n, const int m,
                                                               const double* __restrict__ xTraj,
@@ -177,6 +227,21 @@ extern "C" int zm_quadratize_cost_f64(const zm_quadcost_t* cost, int n, int m, c
         hipLaunchKernelGGL(zm::quadratize_cost_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, *cost, n, m,
                            xTraj, uTraj, (const int*)active, c, c_x, c_u, v, v_x, (long)batch, T);
     }
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+
+extern "C" int zm_quadratic_dynamics_f64(const zm_model_t* model, const double* xTraj, const double* uTraj,
+                                         const int32_t* active, double* f_xx, double* f_ux, double* f_uu, int64_t batch,
+                                         int T, void* stream) {
+    zm_model_t md;
+    int rc = zm_check_model(model, md, "zm_quadratic_dynamics_f64");
+    if (rc) return rc;
+    if (!xTraj || !uTraj || !f_xx || !f_ux || !f_uu) return zm::set_error(ZM_EINVAL, "zm_quadratic_dynamics_f64: null pointer");
+    if (batch < 0 || T < 1) return zm::set_error(ZM_EINVAL, "zm_quadratic_dynamics_f64: bad size");
+    if (batch == 0) return ZM_OK;
+    hipLaunchKernelGGL(zm::quadratic_dynamics_kernel, dim3((unsigned)(batch * T)), dim3(64), 0, (hipStream_t)stream, md, xTraj,
+                       uTraj, (const int*)active, f_xx, f_ux, f_uu, (long)batch, T);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }

@@ -52,6 +52,41 @@ __device__ __forceinline__ double zsin(double a) { return sin(a); }
 __device__ __forceinline__ double zcos(double a) { return cos(a); }
 __device__ __forceinline__ double ztan(double a) { return tan(a); }
 
+// ---- hyper-dual number: value, two first-order parts and the mixed second-order part; f(x + e_a eps1 + e_b eps2)
+//      carries d2 f / dz_a dz_b in .d12 exactly (no truncation error) -- the role of jax.hessian (pytrees.py:180-186)
+struct Hyper {
+    double v, d1, d2, d12;
+};
+__device__ __forceinline__ Hyper operator+(Hyper a, Hyper b) { return {a.v + b.v, a.d1 + b.d1, a.d2 + b.d2, a.d12 + b.d12}; }
+__device__ __forceinline__ Hyper operator-(Hyper a, Hyper b) { return {a.v - b.v, a.d1 - b.d1, a.d2 - b.d2, a.d12 - b.d12}; }
+__device__ __forceinline__ Hyper operator-(Hyper a) { return {-a.v, -a.d1, -a.d2, -a.d12}; }
+__device__ __forceinline__ Hyper operator*(Hyper a, Hyper b) {
+    return {a.v * b.v, a.d1 * b.v + a.v * b.d1, a.d2 * b.v + a.v * b.d2,
+            (a.d12 * b.v + a.d1 * b.d2) + (a.d2 * b.d1 + a.v * b.d12)};
+}
+__device__ __forceinline__ Hyper hyper_fn(Hyper a, double f, double fp, double fpp) {  // chain rule for a unary function
+    return {f, fp * a.d1, fp * a.d2, fp * a.d12 + fpp * (a.d1 * a.d2)};
+}
+__device__ __forceinline__ Hyper hyper_inv(Hyper b) {
+    const double g = 1.0 / b.v;
+    return hyper_fn(b, g, -g * g, 2.0 * g * g * g);
+}
+__device__ __forceinline__ Hyper operator/(Hyper a, Hyper b) { return a * hyper_inv(b); }
+__device__ __forceinline__ Hyper operator+(Hyper a, double b) { return {a.v + b, a.d1, a.d2, a.d12}; }
+__device__ __forceinline__ Hyper operator+(double a, Hyper b) { return {a + b.v, b.d1, b.d2, b.d12}; }
+__device__ __forceinline__ Hyper operator-(Hyper a, double b) { return {a.v - b, a.d1, a.d2, a.d12}; }
+__device__ __forceinline__ Hyper operator-(double a, Hyper b) { return {a - b.v, -b.d1, -b.d2, -b.d12}; }
+__device__ __forceinline__ Hyper operator*(Hyper a, double b) { return {a.v * b, a.d1 * b, a.d2 * b, a.d12 * b}; }
+__device__ __forceinline__ Hyper operator*(double a, Hyper b) { return {a * b.v, a * b.d1, a * b.d2, a * b.d12}; }
+__device__ __forceinline__ Hyper operator/(Hyper a, double b) { return {a.v / b, a.d1 / b, a.d2 / b, a.d12 / b}; }
+__device__ __forceinline__ Hyper operator/(double a, Hyper b) { return a * hyper_inv(b); }
+__device__ __forceinline__ Hyper zsin(Hyper a) { const double s_ = sin(a.v), c_ = cos(a.v); return hyper_fn(a, s_, c_, -s_); }
+__device__ __forceinline__ Hyper zcos(Hyper a) { const double s_ = sin(a.v), c_ = cos(a.v); return hyper_fn(a, c_, -s_, -c_); }
+__device__ __forceinline__ Hyper ztan(Hyper a) {
+    const double t = tan(a.v), q = 1.0 + t * t;
+    return hyper_fn(a, t, q, 2.0 * t * q);
+}
+
 // ---- quadcopter (zopt/quadcopter.py) ---------------------------------------------------------------------------
 // state [u,v,w,p,q,r,phi,theta,psi,x,y,z], control [thrust,mx,my,mz]; g = 9.807, mass = 2.5, I = eye(3) (:15-18).
 // Wind is zero (the iLQR / MPC demos roll out without wind: demos/iterativeLqr.py:35).

@@ -10,12 +10,10 @@
 // computed by K/2 lanes, then every lane applies them to its share of the column pairs (A, V) and of the row pairs (A).
 // Sweeps stop when a whole sweep found every |a_pq| <= 2^-52 * sqrt(|a_pp a_qq|) (quadratic convergence: one extra
 // sweep at most), or after 20 sweeps.
+#include "jacobi16.h"
 #include "zm_common.h"
 
 namespace zm {
-
-constexpr int PK = 16;   // max matrix size
-constexpr int PLD = 17;  // padded leading dimension in LDS
 
 // element accessors of the (possibly block-stored) symmetric matrix
 struct PlainMat {
@@ -44,108 +42,21 @@ struct StackedCost {  // [[c_xx, c_ux^T],[c_ux, c_uu]]   (ilqrUtils.py:230)
     }
 };
 
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 template <class Mat>
 __global__ __launch_bounds__(64) void psd_project_kernel(const Mat M, const int k, const double eps, const long count) {
-    __shared__ double As[PK * PLD], Vs[PK * PLD], cs[PK];  // cs: (c, s) of the K/2 rotations of a round
+    __shared__ double As[PK * PLD], Vs[PK * PLD], cs[PK];
     __shared__ int pq[PK];
     const int lane = threadIdx.x;
     const long mat = blockIdx.x;
     if (mat >= count) return;
-    const int K = (k + 1) & ~1;  // even number of round-robin players; index k (if k is odd) is a bye
-
-    // load, symmetrise (jnp.linalg.eigh: symmetrize_input=True), V = I
+    // load and symmetrise (jnp.linalg.eigh: symmetrize_input=True)
     for (int e = lane; e < k * k; e += 64) {
         const int i = e / k, j = e % k;
         As[i * PLD + j] = 0.5 * (M.load(mat, i, j) + M.load(mat, j, i));
-        Vs[i * PLD + j] = (i == j) ? 1.0 : 0.0;
     }
     wave_lds_sync();
-
-    for (int sweep = 0; sweep < 20; ++sweep) {
-        bool rotated = false;
-        for (int r = 0; r < K - 1; ++r) {
-            // lanes 0..K/2-1: pair `lane` of round r (circle method) and its rotation angle
-            bool rot = false;
-            if (lane < K / 2) {
-                int p, q;
-                if (lane == 0) {
-                    p = K - 1;
-                    q = r;
-                } else {
-                    p = (r + lane) % (K - 1);
-                    q = (r - lane + (K - 1)) % (K - 1);
-                }
-                if (p > q) {
-                    const int t = p;
-                    p = q;
-                    q = t;
-                }
-                double c = 1.0, s = 0.0;
-                if (q < k) {
-                    const double app = As[p * PLD + p], aqq = As[q * PLD + q], apq = As[p * PLD + q];
-                    if (apq != 0.0 && __builtin_fabs(apq) > 0x1p-52 * __builtin_sqrt(__builtin_fabs(app * aqq))) {
-                        const double tau = (aqq - app) / (2.0 * apq);
-                        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (__builtin_fabs(tau) + __builtin_sqrt(1.0 + tau * tau));
-                        c = 1.0 / __builtin_sqrt(1.0 + t * t);
-                        s = t * c;
-                        rot = true;
-                    }
-                } else {
-                    q = p;  // bye: identity on a single index
-                }
-                pq[2 * lane] = p;
-                pq[2 * lane + 1] = q;
-                cs[2 * lane] = c;
-                cs[2 * lane + 1] = s;
-            }
-            rotated |= (__ballot(rot) != 0ull);
-            wave_lds_sync();
-            // columns p,q of A and V:  X[:, p] <- c X[:,p] - s X[:,q],  X[:, q] <- s X[:,p] + c X[:,q]
-            for (int e = lane; e < (K / 2) * k; e += 64) {
-                const int pr = e / k, i = e % k;
-                const int p = pq[2 * pr], q = pq[2 * pr + 1];
-                const double c = cs[2 * pr], s = cs[2 * pr + 1];
-                if (p != q) {
-                    const double ap = As[i * PLD + p], aq = As[i * PLD + q];
-                    As[i * PLD + p] = c * ap - s * aq;
-                    As[i * PLD + q] = s * ap + c * aq;
-                    const double vp = Vs[i * PLD + p], vq = Vs[i * PLD + q];
-                    Vs[i * PLD + p] = c * vp - s * vq;
-                    Vs[i * PLD + q] = s * vp + c * vq;
-                }
-            }
-            wave_lds_sync();
-            // rows p,q of A
-            for (int e = lane; e < (K / 2) * k; e += 64) {
-                const int pr = e / k, j = e % k;
-                const int p = pq[2 * pr], q = pq[2 * pr + 1];
-                const double c = cs[2 * pr], s = cs[2 * pr + 1];
-                if (p != q) {
-                    const double ap = As[p * PLD + j], aq = As[q * PLD + j];
-                    As[p * PLD + j] = c * ap - s * aq;
-                    As[q * PLD + j] = s * ap + c * aq;
-                }
-            }
-            wave_lds_sync();
-        }
-        if (!rotated) break;
-    }
-    // A <- V max(w, eps) V^T
-    for (int e = lane; e < k * k; e += 64) {
-        const int i = e / k, j = e % k;
-        double acc = 0.0;
-        for (int t = 0; t < k; ++t) {
-            const double w = As[t * PLD + t];
-            acc = __builtin_fma(Vs[i * PLD + t] * (w > eps ? w : eps), Vs[j * PLD + t], acc);
-        }
-        M.store(mat, i, j, acc);
-    }
+    psd_project_lds(As, Vs, cs, pq, k, eps, lane);
+    for (int e = lane; e < k * k; e += 64) M.store(mat, e / k, e % k, As[(e / k) * PLD + (e % k)]);
 }
 
 }  // namespace zm

@@ -12,8 +12,8 @@ import numpy as np
 from . import _arrays as arr
 from . import _lib
 from . import models as _models
-from .pytrees import (AffineDynamics, AffinePolicy, QuadraticCostFunction, QuadraticValueFunction,  # noqa: F401
-                      Trajectory)
+from .pytrees import (AffineDynamics, AffinePolicy, QuadraticCostFunction, QuadraticDynamics,  # noqa: F401
+                      QuadraticValueFunction, Trajectory)
 
 try:
     import torch
@@ -186,6 +186,46 @@ def _registered_cost(runningCost, terminalCost):
                     ".runningCost / .terminalCost methods); arbitrary Python callables cannot run inside a HIP kernel")
 
 
+def backwardPass_ddp(dynamics, cost, Vf):
+    """Backwards pass of the DDP algorithm (reference ilqrUtils.py:209-214, step :184-206, :237-251).
+
+    Arguments
+    ---------
+        dynamics : QuadraticDynamics(f, f_x (..., N, n, n), f_u (..., N, n, m), f_xx (..., N, n, n, n),
+                   f_ux (..., N, n, m, n), f_uu (..., N, n, m, m))
+        cost : QuadraticCostFunction, Vf : QuadraticValueFunction   (as backwardPass_ilqr)
+
+    Returns
+    -------
+        AffinePolicy(l (..., N, m), L (..., N, m, n))
+    """
+    _, f_x, f_u, f_xx, f_ux, f_uu = _fields(dynamics)
+    c, c_x, c_u, c_xx, c_ux, c_uu = _fields(cost)
+    v, v_x, v_xx = _fields(Vf)
+    shp = _shape(f_u)
+    if len(shp) < 3:
+        raise ValueError("f_u must have shape (..., N, n, m)")
+    lead, (N, n, m) = shp[:-3], shp[-3:]
+    expect = {"f_x": (f_x, lead + (N, n, n)), "f_xx": (f_xx, lead + (N, n, n, n)), "f_ux": (f_ux, lead + (N, n, m, n)),
+              "f_uu": (f_uu, lead + (N, n, m, m)), "c_x": (c_x, lead + (N, n)), "c_u": (c_u, lead + (N, m)),
+              "c_xx": (c_xx, lead + (N, n, n)), "c_ux": (c_ux, lead + (N, m, n)), "c_uu": (c_uu, lead + (N, m, m)),
+              "v_x": (v_x, lead + (n,)), "v_xx": (v_xx, lead + (n, n))}
+    for name, (X, s_) in expect.items():
+        if _shape(X) != s_:
+            raise ValueError(f"{name} has shape {_shape(X)}, expected {s_}")
+    dt = torch.float64
+    dev = [arr.to_device(X, dt) for X in (f_x, f_u, f_xx, f_ux, f_uu, c_x, c_u, c_xx, c_ux, c_uu, v_x, v_xx)]
+    batch = 1
+    for d in lead:
+        batch *= int(d)
+    dl = torch.empty(lead + (N, m), dtype=dt, device=dev[0].device)
+    dL = torch.empty(lead + (N, m, n), dtype=dt, device=dev[0].device)
+    rc = _lib.lib().zm_ddp_backward_f64(*[t.data_ptr() for t in dev], None, 0, dl.data_ptr(), dL.data_ptr(), batch, N, n, m,
+                                        ctypes.c_void_p(arr.stream_ptr(dev[0])))
+    _lib.check(rc, "backwardPass_ddp")
+    return AffinePolicy(arr.result_like(dl, f_x), arr.result_like(dL, f_x))
+
+
 def iterativeLqr(dynamics, runningCost, terminalCost, x0, uGuess, maxIter=100, tol=1e-3):
     """Iterative LQR algorithm (reference ilqrUtils.py:260-327), batched and device-resident.
 
@@ -210,6 +250,17 @@ def iterativeLqr(dynamics, runningCost, terminalCost, x0, uGuess, maxIter=100, t
     16-way line-search rollout, `converged = |J - J_new| <= tol`.  Converged trajectories drop out of later iterations
     (the reference under vmap would run every lane to the slowest).
     """
+    return _ilqr_or_ddp(dynamics, runningCost, terminalCost, x0, uGuess, maxIter, tol, ddp=False)
+
+
+def differentialDynamicProgramming(dynamics, runningCost, terminalCost, x0, uGuess, maxIter=100, tol=1e-3):
+    """Differential dynamic programming algorithm (reference ilqrUtils.py:330-397): `iterativeLqr` with the second-order
+    expansion of the dynamics (QuadraticDynamics.from_trajectory, :365) and `backwardPass_ddp` (:373).  Same arguments
+    and return values as `iterativeLqr`."""
+    return _ilqr_or_ddp(dynamics, runningCost, terminalCost, x0, uGuess, maxIter, tol, ddp=True)
+
+
+def _ilqr_or_ddp(dynamics, runningCost, terminalCost, x0, uGuess, maxIter, tol, ddp):
     model = dynamics
     if not hasattr(model, "c_struct"):
         raise TypeError("dynamics must be a registered device model (zopt_amd.models.*)")
@@ -260,6 +311,10 @@ def iterativeLqr(dynamics, runningCost, terminalCost, x0, uGuess, maxIter=100, t
     c_x = torch.empty((B, N, n), dtype=dt, device=dev)
     c_u = torch.empty((B, N, m), dtype=dt, device=dev)
     v_x = torch.empty((B, n), dtype=dt, device=dev)
+    if ddp:
+        f_xx = torch.empty((B, N, n, n, n), dtype=dt, device=dev)
+        f_ux = torch.empty((B, N, n, m, n), dtype=dt, device=dev)
+        f_uu = torch.empty((B, N, n, m, m), dtype=dt, device=dev)
     converged = torch.zeros(B, dtype=torch.bool, device=dev)
     active = torch.ones(B, dtype=torch.int32, device=dev)
     it = 0
@@ -270,10 +325,18 @@ def iterativeLqr(dynamics, runningCost, terminalCost, x0, uGuess, maxIter=100, t
         _lib.check(lib.zm_quadratize_cost_f64(pcs, n, m, xT.data_ptr(), uT.data_ptr(), ap, None, c_x.data_ptr(),
                                               c_u.data_ptr(), None, v_x.data_ptr(), None, None, None, None, B, N, st),
                    "iterativeLqr: quadratize")
-        _lib.check(lib.zm_ilqr_backward_ex_f64(f_x.data_ptr(), f_u.data_ptr(), c_x.data_ptr(), c_u.data_ptr(),
-                                               c_xx.data_ptr(), c_ux.data_ptr(), c_uu.data_ptr(), v_x.data_ptr(),
-                                               v_xx.data_ptr(), ap, 1, l.data_ptr(), L.data_ptr(), B, N, n, m, st),
-                   "iterativeLqr: backward pass")
+        if ddp:
+            _lib.check(lib.zm_quadratic_dynamics_f64(pmd, xT.data_ptr(), uT.data_ptr(), ap, f_xx.data_ptr(),
+                                                     f_ux.data_ptr(), f_uu.data_ptr(), B, N, st), "DDP: quadratic dynamics")
+            _lib.check(lib.zm_ddp_backward_f64(f_x.data_ptr(), f_u.data_ptr(), f_xx.data_ptr(), f_ux.data_ptr(),
+                                               f_uu.data_ptr(), c_x.data_ptr(), c_u.data_ptr(), c_xx.data_ptr(),
+                                               c_ux.data_ptr(), c_uu.data_ptr(), v_x.data_ptr(), v_xx.data_ptr(), ap, 1,
+                                               l.data_ptr(), L.data_ptr(), B, N, n, m, st), "DDP: backward pass")
+        else:
+            _lib.check(lib.zm_ilqr_backward_ex_f64(f_x.data_ptr(), f_u.data_ptr(), c_x.data_ptr(), c_u.data_ptr(),
+                                                   c_xx.data_ptr(), c_ux.data_ptr(), c_uu.data_ptr(), v_x.data_ptr(),
+                                                   v_xx.data_ptr(), ap, 1, l.data_ptr(), L.data_ptr(), B, N, n, m, st),
+                       "iterativeLqr: backward pass")
         _lib.check(lib.zm_rollout_linesearch_f64(pmd, pcs, dx0.data_ptr(), l.data_ptr(), L.data_ptr(), xT.data_ptr(),
                                                  uT.data_ptr(), alphas.data_ptr(), 16, ap, xT2.data_ptr(),
                                                  uT2.data_ptr(), Jn.data_ptr(), None, B, N, st),
