@@ -188,3 +188,42 @@ def test_iterativeLqr_maxiter_and_batch_independence(mods):
     # solving a sub-batch alone gives the same answers: trajectories are independent
     ts, Ls, Js, cs = ilqr.iterativeLqr(model, cost, cost, x0[2:4], ug[2:4])
     assert np.array_equal(ts.xTraj, tf.xTraj[2:4]) and np.array_equal(Ls, Lf[2:4]) and np.array_equal(Js, Jf[2:4])
+
+
+def test_pytree_expansion_constructors():
+    """pytrees.py:72-81, 100-115, 139-153, 180-194: from_function / from_trajectory / fromTerminalCostFunction on
+    registered models against the oracle's complex-step / autograd expansions."""
+    from zopt_amd import models, pytrees
+    rng = np.random.default_rng(11)
+    model = models.QuadcopterEuler(0.1)
+    N = 5
+    xT = 0.3 * rng.standard_normal((3, N + 1, 12))
+    uT = models.QuadcopterEuler.uTrim + 0.3 * rng.standard_normal((3, N, 4))
+    dyn = pytrees.AffineDynamics.from_trajectory(model, pytrees.Trajectory(xT, uT))
+    assert dyn.f.shape == (3, N, 12) and dyn.f_x.shape == (3, N, 12, 12) and dyn.f_u.shape == (3, N, 12, 4)
+    for b in range(3):
+        for k in range(N):
+            f, fx, fu = zo.jacobians(zo.quad_euler_step(0.1), xT[b, k], uT[b, k])
+            assert np.max(np.abs(dyn.f[b, k] - f)) <= 1e-13
+            assert np.max(np.abs(dyn.f_x[b, k] - fx)) <= 1e-12 and np.max(np.abs(dyn.f_u[b, k] - fu)) <= 1e-12
+    one = pytrees.AffineDynamics.from_function(model, xT[0, 0], uT[0, 0])
+    assert one.f.shape == (12,) and one.f_x.shape == (12, 12) and one.f_u.shape == (12, 4)
+    assert np.array_equal(one.f_x, dyn.f_x[0, 0])
+    qd = pytrees.QuadraticDynamics.from_trajectory(model, pytrees.Trajectory(xT[0], uT[0]))
+    ref = zo.quadratic_dynamics_from_trajectory(zo.quad_euler_step_torch(0.1), zo.Trajectory(xT[0], uT[0]))
+    for a, b_ in zip(qd, ref):
+        assert a.shape == np.asarray(b_).shape and np.max(np.abs(a - np.asarray(b_))) <= 1e-10
+    Q, R, Qf = rng.standard_normal((12, 12)), rng.standard_normal((4, 4)), rng.standard_normal((12, 12))
+    cost = models.QuadraticCost(Q, R, Qf)
+    qc = pytrees.QuadraticCostFunction.from_trajectory(cost, pytrees.Trajectory(xT[0], uT[0]))
+    for k in range(N):
+        x, u = xT[0, k], uT[0, k]
+        assert abs(qc.c[k] - (x @ Q @ x + u @ R @ u)) <= 1e-12
+        assert np.max(np.abs(qc.c_x[k] - (Q + Q.T) @ x)) <= 1e-12 and np.max(np.abs(qc.c_u[k] - (R + R.T) @ u)) <= 1e-12
+        assert np.array_equal(qc.c_xx[k], Q + Q.T) and np.array_equal(qc.c_uu[k], R + R.T) and not qc.c_ux[k].any()
+    vf = pytrees.QuadraticValueFunction.fromTerminalCostFunction(cost, xT[0, -1])
+    xf = xT[0, -1]
+    assert vf.v.shape == () and abs(vf.v - xf @ Qf @ xf) <= 1e-12
+    assert np.max(np.abs(vf.v_x - (Qf + Qf.T) @ xf)) <= 1e-12 and np.array_equal(vf.v_xx, Qf + Qf.T)
+    with pytest.raises(TypeError):
+        pytrees.AffineDynamics.from_function(lambda x, u: x, xT[0, 0], uT[0, 0])

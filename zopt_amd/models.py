@@ -66,6 +66,9 @@ class QuadraticCost:
         self.Q = np.ascontiguousarray(np.asarray(Q, dtype=np.float64))
         self.R = np.ascontiguousarray(np.asarray(R, dtype=np.float64))
         self.Qf = self.Q if Qf is None else np.ascontiguousarray(np.asarray(Qf, dtype=np.float64))
+        self.n, self.m = self.Q.shape[0], self.R.shape[0]
+        if self.Q.shape != (self.n, self.n) or self.R.shape != (self.m, self.m) or self.Qf.shape != (self.n, self.n):
+            raise ValueError("QuadraticCost: Q (n,n), R (m,m), Qf (n,n) expected")
         self._dev = None
 
     def runningCost(self, x, u):

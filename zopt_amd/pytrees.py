@@ -1,13 +1,95 @@
 """Array-container mirror of ``zopt.pytrees`` (reference pytrees.py:6-12, 58-69, 84-98, 129-136, 165-177, 207-213).
 
 Same NamedTuple names, field order and per-time-step slicing ``obj[k]``; the fields are NumPy arrays or
-torch-ROCm tensors (optionally with leading batch axes, time axis right after them).  The JAX autodiff
-constructors (``from_function`` / ``from_trajectory``) of the reference are not part of the array-level hot path
-and live in ``zopt_amd.models`` for registered device models instead.
+torch-ROCm tensors (optionally with leading batch axes, time axis right after them).  The Taylor-expansion
+constructors (``from_function`` / ``from_trajectory`` / ``fromTerminalCostFunction``, reference pytrees.py:72-81,
+100-115, 139-153, 180-194) keep their names and argument order; where the reference differentiates an arbitrary
+JAX callable, these take a *registered device model* / cost (``zopt_amd.models``) and run the dual-number kernels
+(``zm_linearize_dynamics_f64``, ``zm_quadratic_dynamics_f64``, ``zm_quadratize_cost_f64``).
 """
 from __future__ import annotations
 
+import ctypes
 from typing import NamedTuple
+
+import numpy as np
+
+
+def _expand(kind, fun, xTraj, uTraj):
+    """Run one of the expansion kernels along (xTraj (...,N+1,n), uTraj (...,N,m)); returns the output tensors shaped
+    like the inputs' leading axes.  kind: 'affine' | 'quadratic' | 'cost' | 'terminal'."""
+    import torch
+    from . import _arrays as arr
+    from . import _lib
+    arr.require_gpu()
+    if not hasattr(fun, "c_struct"):
+        raise TypeError("expected a registered device model / cost (zopt_amd.models.*), got " + type(fun).__name__)
+    n, m = fun.n, fun.m
+    dt = torch.float64
+    x = arr.to_device(xTraj, dt)
+    lead = tuple(x.shape[:-2])
+    N = x.shape[-2] - 1
+    x = x.reshape(-1, N + 1, n).contiguous()
+    if uTraj is None:
+        u = torch.zeros((x.shape[0], max(N, 1), m), dtype=dt, device=x.device)
+    else:
+        u = arr.to_device(uTraj, dt).reshape(-1, N, m).contiguous()
+        if u.shape[0] != x.shape[0]:
+            raise ValueError("xTraj / uTraj batch axes differ")
+    B, dev = x.shape[0], x.device
+    st = ctypes.c_void_p(arr.stream_ptr(x))
+    cs = fun.c_struct()
+    pc = ctypes.addressof(cs)
+    lib = _lib.lib()
+    E = lambda *shape: torch.empty(shape, dtype=dt, device=dev)
+    if kind in ("affine", "quadratic"):
+        f, f_x, f_u = E(B, N, n), E(B, N, n, n), E(B, N, n, m)
+        _lib.check(lib.zm_linearize_dynamics_f64(pc, x.data_ptr(), u.data_ptr(), None, f.data_ptr(), f_x.data_ptr(),
+                                                 f_u.data_ptr(), B, N, st), "AffineDynamics.from_trajectory")
+        outs = [f, f_x, f_u]
+        if kind == "quadratic":
+            f_xx, f_ux, f_uu = E(B, N, n, n, n), E(B, N, n, m, n), E(B, N, n, m, m)
+            _lib.check(lib.zm_quadratic_dynamics_f64(pc, x.data_ptr(), u.data_ptr(), None, f_xx.data_ptr(),
+                                                     f_ux.data_ptr(), f_uu.data_ptr(), B, N, st),
+                       "QuadraticDynamics.from_trajectory")
+            outs += [f_xx, f_ux, f_uu]
+        outs = [o.reshape(lead + tuple(o.shape[1:])) for o in outs]
+    else:
+        c, c_x, c_u, v, v_x = E(B, N), E(B, N, n), E(B, N, m), E(B), E(B, n)
+        c_xx, c_ux, c_uu, v_xx = E(n, n), E(m, n), E(m, m), E(n, n)
+        _lib.check(lib.zm_quadratize_cost_f64(pc, n, m, x.data_ptr(), u.data_ptr(), None, c.data_ptr(), c_x.data_ptr(),
+                                              c_u.data_ptr(), v.data_ptr(), v_x.data_ptr(), c_xx.data_ptr(),
+                                              c_ux.data_ptr(), c_uu.data_ptr(), v_xx.data_ptr(), B, N, st),
+                   "QuadraticCostFunction.from_trajectory")
+        if kind == "cost":
+            outs = [c, c_x, c_u] + [h.expand((B, N) + tuple(h.shape)).contiguous() for h in (c_xx, c_ux, c_uu)]
+            outs = [o.reshape(lead + tuple(o.shape[1:])) for o in outs]
+        else:     # terminal cost at x_N; a dummy time axis keeps _point's squeeze uniform
+            outs = [v[:, None], v_x[:, None], v_xx.expand((B, 1, n, n)).contiguous()]
+            outs = [o.reshape(lead + tuple(o.shape[1:])) for o in outs]
+    return [arr.result_like(o, xTraj) for o in outs]
+
+
+def _point(kind, fun, x0, u0):
+    """Expansion about a single point (or a batch of points): a length-1 trajectory with the time axis squeezed."""
+    shp = tuple(x0.shape) if hasattr(x0, "shape") else np.shape(x0)
+    xs = _stack2(x0)
+    us = None if u0 is None else _unsq(u0)
+    outs = _expand(kind, fun, xs, us)
+    k = len(shp) - 1
+    return [o[(slice(None),) * k + (0,)] for o in outs]
+
+
+def _unsq(a):
+    return a.unsqueeze(-2) if hasattr(a, "unsqueeze") else np.asarray(a)[..., None, :]
+
+
+def _stack2(x):
+    """(..., n) -> (..., 2, n): x_0 = x, x_1 = x (the kernels take N+1 states for N steps)"""
+    if hasattr(x, "unsqueeze"):
+        return x.unsqueeze(-2).expand(tuple(x.shape[:-1]) + (2, x.shape[-1]))
+    x = np.asarray(x)
+    return np.broadcast_to(x[..., None, :], x.shape[:-1] + (2, x.shape[-1]))
 
 
 def _slice(tup, k):
@@ -33,6 +115,12 @@ class QuadraticValueFunction(NamedTuple):
         v, v_x, v_xx = tuple.__iter__(self)
         return v + v_x.T @ x + 0.5 * x.T @ v_xx @ x
 
+    @classmethod
+    def fromTerminalCostFunction(cls, costFun, xf):
+        """Quadratic value function of the terminal cost about the final state xf (..., n)   (pytrees.py:72-81)"""
+        v, v_x, v_xx = _point("terminal", costFun, xf, None)
+        return cls(v, v_x, v_xx)
+
 
 class QuadraticCostFunction(NamedTuple):
     """(c, c_x, c_u, c_xx, c_ux, c_uu)"""
@@ -42,6 +130,16 @@ class QuadraticCostFunction(NamedTuple):
     c_xx: object
     c_ux: object
     c_uu: object
+
+    @classmethod
+    def from_function(cls, costFun, x0, u0):
+        """Second-order expansion of the running cost about (x0, u0)   (pytrees.py:100-107)"""
+        return cls(*_point("cost", costFun, x0, u0))
+
+    @classmethod
+    def from_trajectory(cls, costFun, traj):
+        """Second-order expansion of the running cost about (xTraj[:-1], uTraj)   (pytrees.py:109-115)"""
+        return cls(*_expand("cost", costFun, tuple.__getitem__(traj, 0), tuple.__getitem__(traj, 1)))
 
     def __call__(self, x, u, k=None):
         c, c_x, c_u, c_xx, c_ux, c_uu = tuple.__iter__(self)
@@ -60,6 +158,16 @@ class AffineDynamics(NamedTuple):
     f: object
     f_x: object
     f_u: object
+
+    @classmethod
+    def from_function(cls, dynFun, x0, u0):
+        """First-order expansion of the registered model about (x0, u0)   (pytrees.py:139-145)"""
+        return cls(*_point("affine", dynFun, x0, u0))
+
+    @classmethod
+    def from_trajectory(cls, dynFun, traj):
+        """First-order expansion about (xTraj[:-1], uTraj); xTraj (..., N+1, n), uTraj (..., N, m)   (pytrees.py:147-153)"""
+        return cls(*_expand("affine", dynFun, tuple.__getitem__(traj, 0), tuple.__getitem__(traj, 1)))
 
     def __call__(self, x, u, k=None):
         f, f_x, f_u = tuple.__iter__(self)
@@ -81,6 +189,16 @@ class QuadraticDynamics(NamedTuple):
     f_xx: object
     f_ux: object
     f_uu: object
+
+    @classmethod
+    def from_function(cls, dynFun, x0, u0):
+        """Second-order expansion of the registered model about (x0, u0)   (pytrees.py:180-186)"""
+        return cls(*_point("quadratic", dynFun, x0, u0))
+
+    @classmethod
+    def from_trajectory(cls, dynFun, traj):
+        """Second-order expansion about (xTraj[:-1], uTraj)   (pytrees.py:188-194)"""
+        return cls(*_expand("quadratic", dynFun, tuple.__getitem__(traj, 0), tuple.__getitem__(traj, 1)))
 
     def __call__(self, x, u, k=None):
         f, f_x, f_u, f_xx, f_ux, f_uu = tuple.__iter__(self)
