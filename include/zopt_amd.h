@@ -61,6 +61,15 @@ int zm_lqr_backward_affine_f64(const double* A, const double* B, const double* d
                                const double* H, const double* q, const double* r, double* L, double* l,
                                int64_t batch, int T, int n, int m, void* stream);
 
+/* fp32 batched finite-horizon LQR backward sweep for large states (n <= 64, m <= 16): fp32 MFMA tile kernel.
+ * Replaces: zopt/lqrUtils.py:144-173 discreteFiniteHorizonLqr when JAX runs in its default fp32 mode (x64 disabled, quirk Q8);
+ *           the "large-state stress" shape n=64, m=16, T=200 of BASELINE configs[4].
+ * in : A (batch,T,n,n)  B (batch,T,n,m)  Q (batch,T,n,n)  R (batch,T,m,m)   [device, C-contiguous float]
+ * out: L (batch,T,m,n)
+ */
+int zm_lqr_backward_f32(const float* A, const float* B, const float* Q, const float* R, float* L, int64_t batch, int T, int n,
+                        int m, void* stream);
+
 /* zm_lqr_backward_f64 with HOST pointers (NumPy arrays): allocates device staging, copies in, solves, copies L back. */
 int zm_lqr_backward_host_f64(const double* A, const double* B, const double* Q, const double* R, double* L,
                              int64_t batch, int T, int n, int m);

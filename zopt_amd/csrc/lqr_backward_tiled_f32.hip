@@ -1,0 +1,302 @@
+// K1-T  lqr_backward_tiled_f32 -- finite-horizon LQR backward Riccati sweep for LARGE states (n <= 64, m <= 16), fp32, gfx950.
+//
+// Replaces zopt/lqrUtils.py:144-173 discreteFiniteHorizonLqr at the "large-state stress" shape of BASELINE configs[4]
+// (n = 64, m = 16, T = 200, fp32): per trajectory
+//     V <- Q[T-1];  for k = T-1..0:  L_k = solve(R_k + B_k^T V B_k, B_k^T V A_k)                     (:168)
+//                                    V   = Q_k + L_k^T R_k L_k + (A_k - B_k L_k)^T V (A_k - B_k L_k)   (:169, Joseph form)
+// At this shape the sweep is a chain of dense 64x64 contractions (1.7 Mflop per step against 42 kB of operands, 40 flop/B):
+// it is bound by the fp32 matrix pipe, not by HBM, so the products run on v_mfma_f32_16x16x4_f32.
+//
+// One wave64 per trajectory (one wave per SIMD, all 512 registers): the value matrix V (16 tiles), the step's
+// F = [A_k | B_k] (20 tiles) and Y = V^T F (20 tiles) live in registers as 16x16 tiles in the MFMA accumulator layout
+//     lane l = (g = l >> 4, c = l & 15),  tile register r  <->  X[4g + r][c]                     ("D layout").
+// With the K index of a product permuted consistently (K-step s of lane group g <-> row 4g+s) a D-layout tile is directly the
+// B operand of the next product and, read as the A operand, its transpose:  op(X, Y) = X^T Y  costs 4 MFMAs and no lane
+// movement.  Per step (NT = n/16 tile rows, u-index = one tile):
+//     Y_B = V^T B                               4 NT^2   MFMA
+//     S   = Y_B^T F + [0 | R] = [Sux | Suu]     4 NT(NT+1)
+//     Y_A = V^T A                               4 NT^3
+//     L   = solve(Suu, Sux)                     LU with partial pivoting, resident in LDS, one lane per column
+//     Acl = A + B(-L),  -RL = R(-L)             4 NT^2 + 4 NT     (B^T, R^T tiles: transposed through LDS)
+//     W   = Y_A + Y_B(-L) = V^T Acl             4 NT^2
+//     V'  = Q + (-L)^T(-RL) + W^T Acl           4 NT^2 + 4 NT^3           (exact for nonsymmetric V, Q, R as well)
+// = 864 MFMAs per step at NT = 4.  Operands of step k-1 are fetched into a second register set while step k computes.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "zm_common.h"
+
+namespace zm {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void t_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// acc + X^T Y for D-layout tiles
+__device__ __forceinline__ f4 op(const f4 x, const f4 y, f4 acc) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[s], y[s], acc, 0, 0, 0);
+    return acc;
+}
+
+// tile (K, J) of a row-major (nrows x ncols) matrix in D layout; out-of-range elements read as `diag` on the diagonal, else 0
+template <bool EXACT>
+__device__ __forceinline__ f4 load_tile(const float* __restrict__ X, const int nrows, const int ncols, const int K, const int J,
+                                        const int g, const int c, const float diag = 0.f) {
+    f4 t;
+    const int col = 16 * J + c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * K + 4 * g + r;
+        if constexpr (EXACT) {
+            t[r] = X[row * ncols + col];
+        } else {
+            const bool ok = row < nrows && col < ncols;
+            const float v = X[ok ? row * ncols + col : 0];
+            t[r] = ok ? v : ((row == col) ? diag : 0.f);
+        }
+    }
+    return t;
+}
+
+constexpr int TLD = 20;  // row stride of a transpose buffer (floats): 80 B rows keep the b128 reads 16 B-aligned
+
+__device__ __forceinline__ void tile_to_lds(float* buf, const f4 t, const int g, const int c) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) buf[(4 * g + r) * TLD + c] = t[r];
+}
+// the transposed tile: out[r] = X[c][4g + r]
+__device__ __forceinline__ f4 tile_from_lds_T(const float* buf, const int g, const int c) {
+    return *reinterpret_cast<const f4*>(buf + c * TLD + 4 * g);
+}
+
+template <int NT, bool EXACT>
+__global__ __launch_bounds__(64) void lqr_backward_tiled_f32(const float* __restrict__ A, const float* __restrict__ B,
+                                                             const float* __restrict__ Q, const float* __restrict__ R,
+                                                             float* __restrict__ L, const long batch, const int T, const int n,
+                                                             const int m) {
+    constexpr int NP = 16 * NT;       // padded state dimension
+    constexpr int SLD = NP + 16 + 4;  // row stride of the solve buffer [Sux (NP) | Suu (16) | pad]
+    __shared__ __attribute__((aligned(16))) float Sb[16 * SLD];
+    __shared__ __attribute__((aligned(16))) float Tb[2 * NT + 1][16 * TLD];
+    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    // Ownership inside the LDS-resident solve: lane j < NP owns column j of Sux, lane c < 16 owns column c of Suu.  Every
+    // read-modify-write of an LDS word is done by its ONE owner: copies kept by several lanes are not safe, because the
+    // compiler may sink the read into divergent branches, and lanes of different branches would then apply the update twice.
+    const int jl = (NT == 4) ? lane : (lane < NP ? lane : NP - 1);   // surplus lanes read the last column and write nothing
+    const bool own_x = (NT == 4) || lane < NP;
+    const bool own_u = lane < 16;
+    const long traj = blockIdx.x;
+    if (traj >= batch) return;
+    const long nn = (long)n * n, nm = (long)n * m, mm = (long)m * m;
+    const float* Ab = A + traj * T * nn;
+    const float* Bb = B + traj * T * nm;
+    const float* Qb = Q + traj * T * nn;
+    const float* Rb = R + traj * T * mm;
+    float* Lb = L + traj * T * nm;
+
+    f4 V[NT][NT], F[NT][NT + 1], Fn[NT][NT + 1], Y[NT][NT + 1], Rt, Rn;
+    // terminal value = last stage cost (lqrUtils.py:172); operands of the first step
+#pragma unroll
+    for (int K = 0; K < NT; ++K) {
+#pragma unroll
+        for (int J = 0; J < NT; ++J) {
+            V[K][J] = load_tile<EXACT>(Qb + (long)(T - 1) * nn, n, n, K, J, g, c);
+            Fn[K][J] = load_tile<EXACT>(Ab + (long)(T - 1) * nn, n, n, K, J, g, c);
+        }
+        Fn[K][NT] = load_tile<EXACT>(Bb + (long)(T - 1) * nm, n, m, K, 0, g, c);
+    }
+    Rn = load_tile<EXACT>(Rb + (long)(T - 1) * mm, m, m, 0, 0, g, c, 1.f);
+
+    for (int k = T - 1; k >= 0; --k) {
+#pragma unroll
+        for (int K = 0; K < NT; ++K)
+#pragma unroll
+            for (int J = 0; J <= NT; ++J) F[K][J] = Fn[K][J];
+        Rt = Rn;
+        {  // operands of step k-1 (the last iteration re-reads step 0: no branch around the loads)
+            const int kn = k > 0 ? k - 1 : 0;
+#pragma unroll
+            for (int K = 0; K < NT; ++K) {
+#pragma unroll
+                for (int J = 0; J < NT; ++J) Fn[K][J] = load_tile<EXACT>(Ab + kn * nn, n, n, K, J, g, c);
+                Fn[K][NT] = load_tile<EXACT>(Bb + kn * nm, n, m, K, 0, g, c);
+            }
+            Rn = load_tile<EXACT>(Rb + kn * mm, m, m, 0, 0, g, c, 1.f);
+        }
+        // Y_B = V^T B
+#pragma unroll
+        for (int I = 0; I < NT; ++I) {
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int K = 0; K < NT; ++K) acc = op(V[K][I], F[K][NT], acc);
+            Y[I][NT] = acc;
+        }
+        // S = Y_B^T F + [0 | R]  ->  LDS, row u = 4g+r, columns [Sux | Suu]
+#pragma unroll
+        for (int J = 0; J <= NT; ++J) {
+            f4 acc = (J == NT) ? Rt : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int K = 0; K < NT; ++K) acc = op(Y[K][NT], F[K][J], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Sb[(4 * g + r) * SLD + 16 * J + c] = acc[r];
+        }
+        // tiles that are needed transposed: B_K, Y_B,I, R
+#pragma unroll
+        for (int K = 0; K < NT; ++K) {
+            tile_to_lds(Tb[K], F[K][NT], g, c);
+            tile_to_lds(Tb[NT + K], Y[K][NT], g, c);
+        }
+        tile_to_lds(Tb[2 * NT], Rt, g, c);
+        // Y_A = V^T A   (independent of the solve)
+#pragma unroll
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) {
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int K = 0; K < NT; ++K) acc = op(V[K][I], F[K][J], acc);
+                Y[I][J] = acc;
+            }
+        // V is dead: its registers take Q_k, the accumulator init of V'
+#pragma unroll
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) V[I][J] = load_tile<EXACT>(Qb + k * nn, n, n, I, J, g, c);
+        t_lds_sync();
+
+        // ---- L = solve(Suu, Sux): LU with partial pivoting in LDS (jnp.linalg.solve = getrf/getrs), lane j owns column j of
+        //      Sux (j < NP), every lane group a copy of column c of Suu.
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float pv = (c >= kk) ? __builtin_fabsf(Sb[c * SLD + NP + kk]) : -1.f;
+            int pi = c;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const float ov = __shfl_xor(pv, off, 16);
+                const int oi = __shfl_xor(pi, off, 16);
+                const bool take = (ov > pv) || (ov == pv && oi < pi);   // first largest entry, as isamax
+                pv = take ? ov : pv;
+                pi = take ? oi : pi;
+            }
+            const int p = __builtin_amdgcn_readfirstlane(pi);
+            {   // swap rows kk and p (a no-op when p == kk)
+                const float a0 = Sb[kk * SLD + jl], b0 = Sb[p * SLD + jl];
+                const float a1 = Sb[kk * SLD + NP + c], b1 = Sb[p * SLD + NP + c];
+                t_lds_sync();
+                if (own_x) {
+                    Sb[kk * SLD + jl] = b0;
+                    Sb[p * SLD + jl] = a0;
+                }
+                if (own_u) {
+                    Sb[kk * SLD + NP + c] = b1;
+                    Sb[p * SLD + NP + c] = a1;
+                }
+                t_lds_sync();
+            }
+            const float inv = 1.0f / Sb[kk * SLD + NP + kk];
+            const float pj = Sb[kk * SLD + jl];
+            const float pu = Sb[kk * SLD + NP + c];
+#pragma unroll
+            for (int r = kk + 1; r < 16; ++r) {
+                const float mr = Sb[r * SLD + NP + kk] * inv;
+                const float xj = Sb[r * SLD + jl];
+                const float xu = Sb[r * SLD + NP + c];
+                if (own_x) Sb[r * SLD + jl] = xj - mr * pj;
+                if (own_u && c > kk) Sb[r * SLD + NP + c] = xu - mr * pu;
+            }
+            t_lds_sync();
+        }
+        float x[16];
+#pragma unroll
+        for (int kk = 15; kk >= 0; --kk) {
+            float acc = Sb[kk * SLD + jl];
+#pragma unroll
+            for (int r = kk + 1; r < 16; ++r) acc -= Sb[kk * SLD + NP + r] * x[r];
+            x[kk] = acc / Sb[kk * SLD + NP + kk];
+        }
+        t_lds_sync();
+        // L_k to HBM (row u: 64 consecutive floats across the wave), -L back to LDS for the tile reads
+        if (lane < n) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (EXACT || u < m) Lb[k * nm + (long)u * n + lane] = x[u];
+        }
+        if (own_x) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) Sb[u * SLD + jl] = -x[u];
+        }
+        t_lds_sync();
+        f4 NL[NT], NRL[NT];
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) NL[J][r] = Sb[(4 * g + r) * SLD + 16 * J + c];
+        // -RL = R (-L)
+        {
+            const f4 RT = tile_from_lds_T(Tb[2 * NT], g, c);
+#pragma unroll
+            for (int J = 0; J < NT; ++J) NRL[J] = op(RT, NL[J], f4{0.f, 0.f, 0.f, 0.f});
+        }
+        // Acl = A + B(-L)  (in place),  W = Y_A + Y_B(-L)  (in place)
+#pragma unroll
+        for (int K = 0; K < NT; ++K) {
+            const f4 BT = tile_from_lds_T(Tb[K], g, c);
+            const f4 YT = tile_from_lds_T(Tb[NT + K], g, c);
+#pragma unroll
+            for (int J = 0; J < NT; ++J) {
+                F[K][J] = op(BT, NL[J], F[K][J]);
+                Y[K][J] = op(YT, NL[J], Y[K][J]);
+            }
+        }
+        // V' = Q + (-L)^T(-RL) + W^T Acl
+#pragma unroll
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) {
+                f4 acc = op(NL[I], NRL[J], V[I][J]);
+#pragma unroll
+                for (int K = 0; K < NT; ++K) acc = op(Y[K][I], F[K][J], acc);
+                V[I][J] = acc;
+            }
+        t_lds_sync();   // Sb / Tb are rewritten by the next step
+    }
+}
+
+template <int NT>
+static int launch_tiled(const float* A, const float* B, const float* Q, const float* R, float* L, int64_t batch, int T, int n,
+                        int m, hipStream_t st) {
+    const bool exact = (n == 16 * NT) && (m == 16) && !getenv("ZOPT_AMD_TILED_GENERIC");
+    if (exact)
+        hipLaunchKernelGGL((lqr_backward_tiled_f32<NT, true>), dim3((unsigned)batch), dim3(64), 0, st, A, B, Q, R, L, (long)batch,
+                           T, n, m);
+    else
+        hipLaunchKernelGGL((lqr_backward_tiled_f32<NT, false>), dim3((unsigned)batch), dim3(64), 0, st, A, B, Q, R, L,
+                           (long)batch, T, n, m);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+
+}  // namespace zm
+
+extern "C" int zm_lqr_backward_f32(const float* A, const float* B, const float* Q, const float* R, float* L, int64_t batch,
+                                   int T, int n, int m, void* stream) {
+    if (!A || !B || !Q || !R || !L) return zm::set_error(ZM_EINVAL, "zm_lqr_backward_f32: null pointer");
+    if (batch < 0 || T < 0 || n < 1 || m < 1) return zm::set_error(ZM_EINVAL, "zm_lqr_backward_f32: bad size");
+    if (n > 64 || m > 16)
+        return zm::set_error(ZM_EUNSUPPORTED, "zm_lqr_backward_f32: n=%d, m=%d outside n <= 64, m <= 16", n, m);
+    if (batch > 0x7fffffffLL) return zm::set_error(ZM_EINVAL, "zm_lqr_backward_f32: batch too large for one launch");
+    if (batch == 0 || T == 0) return ZM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    switch ((n + 15) / 16) {
+        case 1: return zm::launch_tiled<1>(A, B, Q, R, L, batch, T, n, m, st);
+        case 2: return zm::launch_tiled<2>(A, B, Q, R, L, batch, T, n, m, st);
+        case 3: return zm::launch_tiled<3>(A, B, Q, R, L, batch, T, n, m, st);
+        default: return zm::launch_tiled<4>(A, B, Q, R, L, batch, T, n, m, st);
+    }
+}

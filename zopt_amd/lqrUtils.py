@@ -54,8 +54,10 @@ def discreteFiniteHorizonLqr(A, B, Q, R, N):
     if N < 1:
         _shape_error("N must be >= 1")
     fp32_in = (arr.is_torch(A) and A.dtype == torch.float32) or (not arr.is_torch(A) and np.asarray(A).dtype == np.float32)
-    # TODO(fp32 kernel): fp32 inputs are computed in fp64 on device and rounded once on output.
-    dt = torch.float64
+    # dtype follows the input arrays (quirk Q8).  fp32 inputs: the small shapes (n <= 12, m <= 4) are computed in fp64 on the
+    # tile-16 kernel and rounded once on output; larger ones (n <= 64, m <= 16) run the native fp32 MFMA tile kernel.
+    native32 = fp32_in and (n > 12 or m > 4)
+    dt = torch.float32 if native32 else torch.float64
     dev = [arr.to_device(X, dt) for X in (A, B, Q, R)]
     # the reference scans xs = arange(N) over the first N steps of each array
     dA, dB, dQ, dR = [x[..., :N, :, :].contiguous() if x.shape[-3] != N else x for x in dev]
@@ -63,10 +65,11 @@ def discreteFiniteHorizonLqr(A, B, Q, R, N):
     for d in lead:
         batch *= int(d)
     dL = torch.empty(lead + (N, m, n), dtype=dt, device=dA.device)
-    rc = _lib.lib().zm_lqr_backward_f64(dA.data_ptr(), dB.data_ptr(), dQ.data_ptr(), dR.data_ptr(), dL.data_ptr(),
-                                        batch, N, n, m, ctypes.c_void_p(arr.stream_ptr(dA)))
+    fn = _lib.lib().zm_lqr_backward_f32 if native32 else _lib.lib().zm_lqr_backward_f64
+    rc = fn(dA.data_ptr(), dB.data_ptr(), dQ.data_ptr(), dR.data_ptr(), dL.data_ptr(), batch, N, n, m,
+            ctypes.c_void_p(arr.stream_ptr(dA)))
     _lib.check(rc, "discreteFiniteHorizonLqr")
-    if fp32_in:
+    if fp32_in and not native32:
         dL = dL.to(torch.float32)
     return arr.result_like(dL, A)
 
