@@ -64,31 +64,46 @@ __device__ __forceinline__ f4 load_tile(const float* __restrict__ X, const int n
     return t;
 }
 
-constexpr int TLD = 20;  // row stride of a transpose buffer (floats): 80 B rows keep the b128 reads 16 B-aligned
+constexpr int TLD = 20;  // row stride of a transpose buffer (floats): 80 B rows keep the b128 accesses 16 B-aligned
 
+// D-layout tile -> LDS, transposed: buf[col * TLD + row]  (one b128 per lane); reading it back with the roles of (g, c)
+// swapped gives the transposed tile, reading TLD-strided columns gives one matrix column per lane.
+__device__ __forceinline__ void tile_to_lds_T(float* buf, const f4 t, const int g, const int c) {
+    *reinterpret_cast<f4*>(buf + c * TLD + 4 * g) = t;
+}
+// D-layout tile -> LDS row-major buf[row * TLD + col]; tile_from_lds_T then returns the transpose: out[r] = X[c][4g + r]
 __device__ __forceinline__ void tile_to_lds(float* buf, const f4 t, const int g, const int c) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) buf[(4 * g + r) * TLD + c] = t[r];
 }
-// the transposed tile: out[r] = X[c][4g + r]
 __device__ __forceinline__ f4 tile_from_lds_T(const float* buf, const int g, const int c) {
     return *reinterpret_cast<const f4*>(buf + c * TLD + 4 * g);
+}
+
+__device__ __forceinline__ float readlane_f(const float v, const int l) {   // wave-uniform copy of lane l's value
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+__device__ __forceinline__ float rcp_nr(const float a) {   // 1/a to fp32 rounding: hardware estimate (1 ulp) + one Newton step
+    const float y = __builtin_amdgcn_rcpf(a);
+    return __builtin_fmaf(__builtin_fmaf(-a, y, 1.0f), y, y);
 }
 
 template <int NT, bool EXACT>
 __global__ __launch_bounds__(64) void lqr_backward_tiled_f32(const float* __restrict__ A, const float* __restrict__ B,
                                                              const float* __restrict__ Q, const float* __restrict__ R,
-                                                             float* __restrict__ L, const long batch, const int T, const int n,
-                                                             const int m) {
-    constexpr int NP = 16 * NT;       // padded state dimension
-    constexpr int SLD = NP + 16 + 4;  // row stride of the solve buffer [Sux (NP) | Suu (16) | pad]
-    __shared__ __attribute__((aligned(16))) float Sb[16 * SLD];
+                                                             float* __restrict__ L, const long batch, const int T, const int n_,
+                                                             const int m_) {
+    constexpr int NP = 16 * NT;  // padded state dimension
+    const int n = EXACT ? NP : n_, m = EXACT ? 16 : m_;
+    // Solve buffer, column-major: element (row u, column j) of [Sux | Suu] at Sc[j * TLD + u]; columns NP..NP+15 are Suu.
+    __shared__ __attribute__((aligned(16))) float Sc[(NP + 16) * TLD];
     __shared__ __attribute__((aligned(16))) float Tb[2 * NT + 1][16 * TLD];
     const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
-    // Ownership inside the LDS-resident solve: lane j < NP owns column j of Sux, lane c < 16 owns column c of Suu.  Every
-    // read-modify-write of an LDS word is done by its ONE owner: copies kept by several lanes are not safe, because the
-    // compiler may sink the read into divergent branches, and lanes of different branches would then apply the update twice.
-    const int jl = (NT == 4) ? lane : (lane < NP ? lane : NP - 1);   // surplus lanes read the last column and write nothing
+    // Ownership inside the LDS-resident (pivoted) solve: lane j < NP owns column j of Sux, lane c < 16 owns column c of Suu.
+    // Every read-modify-write of an LDS word is done by its ONE owner: copies kept by several lanes are not safe, because
+    // the compiler may sink the read into divergent branches, and lanes of different branches would apply the update twice.
+    const int jl = (NT == 4) ? lane : (lane < NP ? lane : NP - 1);  // surplus lanes read the last column and write nothing
     const bool own_x = (NT == 4) || lane < NP;
     const bool own_u = lane < 16;
     const long traj = blockIdx.x;
@@ -137,14 +152,13 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled_f32(const float* __rest
             for (int K = 0; K < NT; ++K) acc = op(V[K][I], F[K][NT], acc);
             Y[I][NT] = acc;
         }
-        // S = Y_B^T F + [0 | R]  ->  LDS, row u = 4g+r, columns [Sux | Suu]
+        // S = Y_B^T F + [0 | R]  ->  LDS, one b128 per tile (rows 4g..4g+3 of column 16J+c)
 #pragma unroll
         for (int J = 0; J <= NT; ++J) {
             f4 acc = (J == NT) ? Rt : f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int K = 0; K < NT; ++K) acc = op(Y[K][NT], F[K][J], acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Sb[(4 * g + r) * SLD + 16 * J + c] = acc[r];
+            tile_to_lds_T(Sc + 16 * J * TLD, acc, g, c);
         }
         // tiles that are needed transposed: B_K, Y_B,I, R
 #pragma unroll
@@ -153,7 +167,20 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled_f32(const float* __rest
             tile_to_lds(Tb[NT + K], Y[K][NT], g, c);
         }
         tile_to_lds(Tb[2 * NT], Rt, g, c);
-        // Y_A = V^T A   (independent of the solve)
+        t_lds_sync();
+        // column j of Sux and column c of Suu into registers
+        float x[16], u[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f4 a = *reinterpret_cast<const f4*>(Sc + jl * TLD + 4 * q);
+            const f4 b = *reinterpret_cast<const f4*>(Sc + (NP + c) * TLD + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                x[4 * q + r] = a[r];
+                u[4 * q + r] = b[r];
+            }
+        }
+        // Y_A = V^T A   (independent of the solve: the scheduler may interleave the two)
 #pragma unroll
         for (int I = 0; I < NT; ++I)
 #pragma unroll
@@ -168,75 +195,102 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled_f32(const float* __rest
         for (int I = 0; I < NT; ++I)
 #pragma unroll
             for (int J = 0; J < NT; ++J) V[I][J] = load_tile<EXACT>(Qb + k * nn, n, n, I, J, g, c);
-        t_lds_sync();
 
-        // ---- L = solve(Suu, Sux): LU with partial pivoting in LDS (jnp.linalg.solve = getrf/getrs), lane j owns column j of
-        //      Sux (j < NP), every lane group a copy of column c of Suu.
+        // ---- L = solve(Suu, Sux).  Fast path: LU WITHOUT row exchanges on registers (row operations are lane-local, the
+        //      multipliers wave-uniform).  Accepted only if every multiplier stayed <= 4 in magnitude (partial pivoting keeps
+        //      them <= 1; for the symmetric positive definite Suu of a regular LQR problem they are far below that), so the
+        //      result differs from jnp.linalg.solve's pivoted LU by rounding only.  Otherwise: pivoted LU in LDS (below).
+        unsigned long long bad = 0ull;
+        float pinv[16];
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
-            float pv = (c >= kk) ? __builtin_fabsf(Sb[c * SLD + NP + kk]) : -1.f;
-            int pi = c;
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-                const float ov = __shfl_xor(pv, off, 16);
-                const int oi = __shfl_xor(pi, off, 16);
-                const bool take = (ov > pv) || (ov == pv && oi < pi);   // first largest entry, as isamax
-                pv = take ? ov : pv;
-                pi = take ? oi : pi;
-            }
-            const int p = __builtin_amdgcn_readfirstlane(pi);
-            {   // swap rows kk and p (a no-op when p == kk)
-                const float a0 = Sb[kk * SLD + jl], b0 = Sb[p * SLD + jl];
-                const float a1 = Sb[kk * SLD + NP + c], b1 = Sb[p * SLD + NP + c];
-                t_lds_sync();
-                if (own_x) {
-                    Sb[kk * SLD + jl] = b0;
-                    Sb[p * SLD + jl] = a0;
-                }
-                if (own_u) {
-                    Sb[kk * SLD + NP + c] = b1;
-                    Sb[p * SLD + NP + c] = a1;
-                }
-                t_lds_sync();
-            }
-            const float inv = 1.0f / Sb[kk * SLD + NP + kk];
-            const float pj = Sb[kk * SLD + jl];
-            const float pu = Sb[kk * SLD + NP + c];
+            const float inv = rcp_nr(u[kk]);
+            pinv[kk] = readlane_f(inv, kk);
 #pragma unroll
             for (int r = kk + 1; r < 16; ++r) {
-                const float mr = Sb[r * SLD + NP + kk] * inv;
-                const float xj = Sb[r * SLD + jl];
-                const float xu = Sb[r * SLD + NP + c];
-                if (own_x) Sb[r * SLD + jl] = xj - mr * pj;
-                if (own_u && c > kk) Sb[r * SLD + NP + c] = xu - mr * pu;
+                const float mv = u[r] * inv;
+                bad |= __ballot(!(__builtin_fabsf(mv) <= 4.0f)) & (0x0001000100010001ull << kk);
+                const float ms = readlane_f(mv, kk);
+                x[r] = __builtin_fmaf(-ms, x[kk], x[r]);
+                u[r] = __builtin_fmaf(-ms, u[kk], u[r]);
             }
-            t_lds_sync();
         }
-        float x[16];
+        bad |= __ballot(!(__builtin_fabsf(pinv[15]) < 3.0e38f)) ;
 #pragma unroll
         for (int kk = 15; kk >= 0; --kk) {
-            float acc = Sb[kk * SLD + jl];
+            float acc = x[kk];
 #pragma unroll
-            for (int r = kk + 1; r < 16; ++r) acc -= Sb[kk * SLD + NP + r] * x[r];
-            x[kk] = acc / Sb[kk * SLD + NP + kk];
+            for (int r = kk + 1; r < 16; ++r) acc = __builtin_fmaf(-readlane_f(u[kk], r), x[r], acc);
+            x[kk] = acc * pinv[kk];
         }
-        t_lds_sync();
-        // L_k to HBM (row u: 64 consecutive floats across the wave), -L back to LDS for the tile reads
+        if (bad != 0ull) {   // wave-uniform, rare: LU with partial pivoting on the copy still in LDS (getrf / getrs order)
+#define S_(r_, j_) Sc[(j_) * TLD + (r_)]
+#pragma unroll 1
+            for (int kk = 0; kk < 16; ++kk) {
+                float pv = (c >= kk) ? __builtin_fabsf(S_(c, NP + kk)) : -1.f;
+                int pi = c;
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    const float ov = __shfl_xor(pv, off, 16);
+                    const int oi = __shfl_xor(pi, off, 16);
+                    const bool take = (ov > pv) || (ov == pv && oi < pi);  // first largest entry, as isamax
+                    pv = take ? ov : pv;
+                    pi = take ? oi : pi;
+                }
+                const int p = __builtin_amdgcn_readfirstlane(pi);
+                {  // swap rows kk and p (a no-op when p == kk)
+                    const float a0 = S_(kk, jl), b0 = S_(p, jl);
+                    const float a1 = S_(kk, NP + c), b1 = S_(p, NP + c);
+                    t_lds_sync();
+                    if (own_x) {
+                        S_(kk, jl) = b0;
+                        S_(p, jl) = a0;
+                    }
+                    if (own_u) {
+                        S_(kk, NP + c) = b1;
+                        S_(p, NP + c) = a1;
+                    }
+                    t_lds_sync();
+                }
+                const float inv = 1.0f / S_(kk, NP + kk);
+                const float pj = S_(kk, jl);
+                const float pu = S_(kk, NP + c);
+#pragma unroll 1
+                for (int r = kk + 1; r < 16; ++r) {
+                    const float mr = S_(r, NP + kk) * inv;
+                    const float xj = S_(r, jl);
+                    const float xu = S_(r, NP + c);
+                    t_lds_sync();
+                    if (own_x) S_(r, jl) = xj - mr * pj;
+                    if (own_u && c > kk) S_(r, NP + c) = xu - mr * pu;
+                }
+                t_lds_sync();
+            }
+#pragma unroll
+            for (int kk = 15; kk >= 0; --kk) {
+                float acc = S_(kk, jl);
+#pragma unroll
+                for (int r = kk + 1; r < 16; ++r) acc -= S_(kk, NP + r) * x[r];
+                x[kk] = acc / S_(kk, NP + kk);
+            }
+            t_lds_sync();
+#undef S_
+        }
+        // L_k to HBM (row u: 64 consecutive floats across the wave), -L back to LDS (b128) for the tile reads
         if (lane < n) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (EXACT || u < m) Lb[k * nm + (long)u * n + lane] = x[u];
+            for (int u_ = 0; u_ < 16; ++u_)
+                if (EXACT || u_ < m) Lb[k * nm + (long)u_ * n + lane] = x[u_];
         }
         if (own_x) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) Sb[u * SLD + jl] = -x[u];
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f4*>(Sc + jl * TLD + 4 * q) = f4{-x[4 * q], -x[4 * q + 1], -x[4 * q + 2], -x[4 * q + 3]};
         }
         t_lds_sync();
         f4 NL[NT], NRL[NT];
 #pragma unroll
-        for (int J = 0; J < NT; ++J)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) NL[J][r] = Sb[(4 * g + r) * SLD + 16 * J + c];
+        for (int J = 0; J < NT; ++J) NL[J] = *reinterpret_cast<const f4*>(Sc + (16 * J + c) * TLD + 4 * g);
         // -RL = R (-L)
         {
             const f4 RT = tile_from_lds_T(Tb[2 * NT], g, c);
@@ -264,7 +318,7 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled_f32(const float* __rest
                 for (int K = 0; K < NT; ++K) acc = op(Y[K][I], F[K][J], acc);
                 V[I][J] = acc;
             }
-        t_lds_sync();   // Sb / Tb are rewritten by the next step
+        t_lds_sync();  // Sc / Tb are rewritten by the next step
     }
 }
 
