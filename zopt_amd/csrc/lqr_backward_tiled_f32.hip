@@ -134,16 +134,6 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled_f32(const float* __rest
 #pragma unroll
             for (int J = 0; J <= NT; ++J) F[K][J] = Fn[K][J];
         Rt = Rn;
-        {  // operands of step k-1 (the last iteration re-reads step 0: no branch around the loads)
-            const int kn = k > 0 ? k - 1 : 0;
-#pragma unroll
-            for (int K = 0; K < NT; ++K) {
-#pragma unroll
-                for (int J = 0; J < NT; ++J) Fn[K][J] = load_tile<EXACT>(Ab + kn * nn, n, n, K, J, g, c);
-                Fn[K][NT] = load_tile<EXACT>(Bb + kn * nm, n, m, K, 0, g, c);
-            }
-            Rn = load_tile<EXACT>(Rb + kn * mm, m, m, 0, 0, g, c, 1.f);
-        }
         // Y_B = V^T B
 #pragma unroll
         for (int I = 0; I < NT; ++I) {
@@ -180,21 +170,26 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled_f32(const float* __rest
                 u[4 * q + r] = b[r];
             }
         }
-        // Y_A = V^T A   (independent of the solve: the scheduler may interleave the two)
+        // Y_A = V^T A (4 NT^3 MFMAs, 32 cycles of matrix pipe each) is independent of the solve.  A wave issues in order, so
+        // the solve's VALU work hides under these MFMAs only if the two are interleaved finely: ya(t) issues MFMA number t of
+        // the Y_A sequence (row-tile I outermost) and closes the scheduling region, so the order written here is the order
+        // executed: one MFMA per elimination / substitution unit.  When row-tile I is complete the V tiles it read (column I)
+        // are dead and take Q_k[*][I], the accumulator init of V'.
+        int yq = 0;   // running MFMA number: a constant at every call once the loops below are unrolled
+        auto ya = [&]() {
+            const int t = yq++;
+            if (t < 4 * NT * NT * NT) {
+                const int s_ = t & 3, K_ = (t >> 2) % NT, J_ = ((t >> 2) / NT) % NT, I_ = (t >> 2) / (NT * NT);
+                const f4 a_ = (K_ == 0 && s_ == 0) ? f4{0.f, 0.f, 0.f, 0.f} : Y[I_][J_];
+                Y[I_][J_] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[K_][I_][s_], F[K_][J_][s_], a_, 0, 0, 0);
+                if ((t + 1) % (4 * NT * NT) == 0) {
 #pragma unroll
-        for (int I = 0; I < NT; ++I)
-#pragma unroll
-            for (int J = 0; J < NT; ++J) {
-                f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int K = 0; K < NT; ++K) acc = op(V[K][I], F[K][J], acc);
-                Y[I][J] = acc;
+                    for (int K = 0; K < NT; ++K) V[K][I_] = load_tile<EXACT>(Qb + k * nn, n, n, K, I_, g, c);
+                }
             }
-        // V is dead: its registers take Q_k, the accumulator init of V'
-#pragma unroll
-        for (int I = 0; I < NT; ++I)
-#pragma unroll
-            for (int J = 0; J < NT; ++J) V[I][J] = load_tile<EXACT>(Qb + k * nn, n, n, I, J, g, c);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        __builtin_amdgcn_sched_barrier(0);
 
         // ---- L = solve(Suu, Sux).  Fast path: LU WITHOUT row exchanges on registers (row operations are lane-local, the
         //      multipliers wave-uniform).  Accepted only if every multiplier stayed <= 4 in magnitude (partial pivoting keeps
@@ -206,6 +201,7 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled_f32(const float* __rest
         for (int kk = 0; kk < 16; ++kk) {
             const float inv = rcp_nr(u[kk]);
             pinv[kk] = readlane_f(inv, kk);
+            ya();
 #pragma unroll
             for (int r = kk + 1; r < 16; ++r) {
                 const float mv = u[r] * inv;
@@ -213,16 +209,22 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled_f32(const float* __rest
                 const float ms = readlane_f(mv, kk);
                 x[r] = __builtin_fmaf(-ms, x[kk], x[r]);
                 u[r] = __builtin_fmaf(-ms, u[kk], u[r]);
+                ya();
             }
         }
-        bad |= __ballot(!(__builtin_fabsf(pinv[15]) < 3.0e38f)) ;
+        bad |= __ballot(!(__builtin_fabsf(pinv[15]) < 3.0e38f));
 #pragma unroll
         for (int kk = 15; kk >= 0; --kk) {
             float acc = x[kk];
 #pragma unroll
-            for (int r = kk + 1; r < 16; ++r) acc = __builtin_fmaf(-readlane_f(u[kk], r), x[r], acc);
+            for (int r = kk + 1; r < 16; ++r) {
+                acc = __builtin_fmaf(-readlane_f(u[kk], r), x[r], acc);
+                ya();
+            }
             x[kk] = acc * pinv[kk];
         }
+#pragma unroll
+        for (int t = 256; t < 4 * NT * NT * NT; ++t) ya();   // (none for NT <= 4)
         if (bad != 0ull) {   // wave-uniform, rare: LU with partial pivoting on the copy still in LDS (getrf / getrs order)
 #define S_(r_, j_) Sc[(j_) * TLD + (r_)]
 #pragma unroll 1
@@ -291,6 +293,18 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled_f32(const float* __rest
         f4 NL[NT], NRL[NT];
 #pragma unroll
         for (int J = 0; J < NT; ++J) NL[J] = *reinterpret_cast<const f4*>(Sc + (16 * J + c) * TLD + 4 * g);
+        {  // operands of step k-1, fetched under the ~15k cycles of MFMAs that follow (the last iteration re-reads step 0:
+           // no branch around the loads); issued only now so that they do not hold 84 registers during the solve
+            const int kn = k > 0 ? k - 1 : 0;
+#pragma unroll
+            for (int K = 0; K < NT; ++K) {
+#pragma unroll
+                for (int J = 0; J < NT; ++J) Fn[K][J] = load_tile<EXACT>(Ab + kn * nn, n, n, K, J, g, c);
+                Fn[K][NT] = load_tile<EXACT>(Bb + kn * nm, n, m, K, 0, g, c);
+            }
+            Rn = load_tile<EXACT>(Rb + kn * mm, m, m, 0, 0, g, c, 1.f);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // all 84 loads in flight before the MFMA stream starts
         // -RL = R (-L)
         {
             const f4 RT = tile_from_lds_T(Tb[2 * NT], g, c);
