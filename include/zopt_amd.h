@@ -217,6 +217,17 @@ int zm_mpc_solve_f64(const double* A, const double* B, const double* K, const do
                      double* uTraj,
                      int32_t* status, int32_t* iters, double* resid, int64_t batch, int N, int n, int m, void* stream);
 
+/* Same, with OSQP-style warm starting (cvxpy's default `warm_start=True`, mpcUtils.py:77): with warm_start != 0 the
+ * workspace must be the one a previous call for the same (batch, N, n, m, rho) left behind; its iterates (box copy y,
+ * scaled dual lam) start the ADMM instead of zeros; warm_start == 2 additionally advances them by one horizon step
+ * (iterate k <- iterate k+1, the last one repeated), the natural guess when x0 is the previous plan's x_1 as in the
+ * receding-horizon loop (demos/lqrMpc.py:41-48).  Only instances whose previous solve ended "optimal" are warm-started. */
+int zm_mpc_solve_warm_f64(const double* A, const double* B, const double* K, const double* Minv, const double* x_lb,
+                          const double* x_ub, const double* u_lb, const double* u_ub, const double* x0, double rho,
+                          double eps_abs, double eps_rel, double eps_prim_inf, int max_iter, int warm_start,
+                          double* workspace, double* xTraj, double* uTraj, int32_t* status, int32_t* iters, double* resid,
+                          int64_t batch, int N, int n, int m, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

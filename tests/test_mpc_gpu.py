@@ -175,7 +175,7 @@ def test_receding_horizon_loop(mpc):
     for _ in range(25):
         x = np.clip(x, -x_ub + 1e-6, x_ub - 1e-6)
         u, traj, status = prob.solve(x, solver="OSQP", eps_prim_inf=1e-3, eps_dual_inf=1e-3, eps_abs=1e-2, eps_rel=1e-2,
-                                     max_iter=2000)      # the demo's options (demos/lqrMpc.py:32)
+                                     max_iter=2000, warm_start=False)      # the demo's options (demos/lqrMpc.py:32)
         assert set(status[alive]) <= {"optimal", "infeasible", "user_limit"}
         for b in np.where(alive & (status == "infeasible"))[0][:2]:
             if checked < 4:
@@ -185,6 +185,56 @@ def test_receding_horizon_loop(mpc):
         x = np.where(alive[:, None], traj.xTraj[:, 1], x)
     assert alive.sum() >= 16
     assert np.all(np.linalg.norm(x[alive, 9:12], axis=1) < d0[alive])      # every surviving instance moved towards the origin
+
+
+def test_warm_start_reuses_previous_iterates(mpc):
+    """cvxpy's default warm_start=True (mpcUtils.py:77 forwards **kwargs): a second solve of the same batch shape starts from
+    the previous ADMM iterates (same x0, tighter tolerance: fewer iterations than from zero); warm_start="shift" advances
+    them by one step for the receding-horizon loop.  Same answers as cold solves within the tolerance; an instance that
+    was not "optimal" last time starts cold again."""
+    prob, (A, B, Q, R, Qf, x_ub, u_ub) = _quad_mpc(mpc, N=25)
+    rng = np.random.default_rng(4)
+    x = np.zeros((16, 12))
+    x[:, 9:12] = rng.uniform(-5, 5, (16, 3))
+    loose = dict(eps_abs=1e-3, eps_rel=1e-3, max_iter=200000)
+    tight = dict(eps_abs=1e-5, eps_rel=1e-5, max_iter=200000)
+    # (a) refine the same problem
+    _, _, s0 = prob.solve(x, warm_start=False, **loose)
+    assert np.all(s0 == "optimal")
+    ur, tr, sr = prob.solve(x, **tight)                   # warm (default)
+    it_refine = prob.last_iterations.copy()
+    uc, tc, sc = prob.solve(x, warm_start=False, **tight)
+    it_cold = prob.last_iterations.copy()
+    assert np.all(sr == "optimal") and np.all(sc == "optimal")
+    assert np.max(np.abs(tr.uTraj - tc.uTraj)) <= 1e-2 and np.max(np.abs(tr.xTraj - tc.xTraj)) <= 1e-2
+    assert it_refine.sum() < it_cold.sum()
+    # cold start is reproducible bit for bit
+    _, tc2, _ = prob.solve(x, warm_start=False, **tight)
+    assert np.array_equal(tc2.uTraj, tc.uTraj) and np.array_equal(prob.last_iterations, it_cold)
+    # (b) receding horizon at the demo's tolerance: x0 <- x_1 of the plan ("assume perfect tracking", demos/lqrMpc.py:47),
+    #     iterates shifted by one step
+    demo = dict(eps_abs=1e-2, eps_rel=1e-2, max_iter=200000)
+    _, t0, s0 = prob.solve(x, warm_start=False, **demo)
+    x1 = t0.xTraj[:, 1]
+    us, ts, ss = prob.solve(x1, warm_start="shift", **demo)
+    it_shift = prob.last_iterations.copy()
+    uc1, tc1, sc1 = prob.solve(x1, warm_start=False, **demo)
+    it_cold1 = prob.last_iterations.copy()
+    assert np.all(s0 == "optimal") and np.all(ss == "optimal") and np.all(sc1 == "optimal")
+    cw = np.array([mo.cost(Q, R, Qf, ts.xTraj[b], ts.uTraj[b]) for b in range(16)])
+    cc = np.array([mo.cost(Q, R, Qf, tc1.xTraj[b], tc1.uTraj[b]) for b in range(16)])
+    assert np.all(np.abs(cw - cc) <= 5e-2 * np.maximum(cc, 1.0))       # both are 1e-2-accurate solutions of the same QP
+    assert it_shift.sum() < 0.5 * it_cold1.sum()
+    _, tc1, _ = prob.solve(x1, warm_start=False, **tight)
+    it_cold1 = prob.last_iterations.copy()
+    # (c) an infeasible instance does not poison the next solve of its slot
+    xb = x1.copy()
+    xb[0, 0] = 5.0                                        # outside its bound
+    _, _, sb = prob.solve(xb, warm_start=False, **tight)
+    assert sb[0] == "infeasible"
+    un, tn, sn = prob.solve(x1, **tight)                  # warm: slot 0 restarts cold
+    assert np.all(sn == "optimal") and np.max(np.abs(tn.uTraj - tc1.uTraj)) <= 1e-2
+    assert prob.last_iterations[0] == it_cold1[0]
 
 
 def test_bad_arguments(mpc):

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--N", type=int, default=30)
     ap.add_argument("--eps", type=float, nargs="+", default=[1e-2, 1e-4])
     ap.add_argument("--max-iter", type=int, default=100000)
+    ap.add_argument("--rh-steps", type=int, default=50)
     args = ap.parse_args()
     import torch
     from zopt_amd import models, mpcUtils, pytrees
@@ -36,7 +37,7 @@ def main():
     torch.cuda.synchronize()
     for eps in args.eps:
         t0 = time.perf_counter()
-        u0, traj, status = prob.solve(tx0, solver="OSQP", eps_abs=eps, eps_rel=eps, max_iter=args.max_iter)
+        u0, traj, status = prob.solve(tx0, solver="OSQP", eps_abs=eps, eps_rel=eps, max_iter=args.max_iter, warm_start=False)
         torch.cuda.synchronize()
         t = time.perf_counter() - t0
         its = prob.last_iterations
@@ -45,6 +46,34 @@ def main():
                           "iters_mean": float(its.mean()), "iters_max": int(its.max()),
                           "instance_horizon_steps_per_s": args.batch * args.N / t,
                           "admm_sweep_steps_per_s": float(its.sum()) * args.N / t}))
+
+
+    # receding-horizon run (50 MPC steps, demos/lqrMpc.py:40-47: clip, solve, x <- xTraj[1]), warm-started
+    lo = torch.as_tensor(-x_ub + 1e-6, device="cuda")
+    hi = torch.as_tensor(x_ub - 1e-6, device="cuda")
+    for warm in (False, "shift"):
+        x = tx0.clone()
+        alive = torch.ones(args.batch, dtype=torch.bool, device="cuda")
+        iters = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.rh_steps):
+            x = torch.minimum(torch.maximum(x, lo), hi)
+            u0, traj, status = prob.solve(x, solver="OSQP", eps_abs=1e-2, eps_rel=1e-2, eps_prim_inf=1e-3, max_iter=4000,
+                                          warm_start=warm)
+            ok = torch.as_tensor(status == "optimal", device="cuda")
+            alive &= ok
+            iters += float(prob.last_iterations.sum())
+            # instances whose QP became infeasible / unsolved are parked at hover so that they stop costing iterations
+            x = torch.where(alive[:, None], traj.xTraj[:, 1], torch.zeros_like(x))
+        torch.cuda.synchronize()
+        t = time.perf_counter() - t0
+        print(json.dumps({"workload": f"receding horizon: {args.rh_steps} MPC steps x {args.batch} instances, N={args.N}, "
+                                      f"eps=1e-2, warm_start={warm}",
+                          "total_ms": t * 1e3, "ms_per_mpc_step": t * 1e3 / args.rh_steps,
+                          "alive_frac": float(alive.double().mean().item()),
+                          "admm_iters_per_solve": iters / (args.rh_steps * args.batch),
+                          "instance_solves_per_s": args.rh_steps * args.batch / t}))
 
 
 if __name__ == "__main__":

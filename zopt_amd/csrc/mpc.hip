@@ -120,6 +120,7 @@ struct MpcArgs {
     const double* x0;
     double rho, eps_abs, eps_rel, eps_pinf;
     int max_iter;
+    int warm;   // 1: the workspace holds the iterates (y, lam) of a previous solve of the same problem family; 2: same, shifted by one step
     double *ws, *xTraj, *uTraj;
     int *status, *iters;
     double* resid;
@@ -155,11 +156,20 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const double* __restrict_
 #pragma unroll
     for (int i = 0; i < NS; ++i) x0_ok &= (x0[i] >= x_lb[i]) && (x0[i] <= x_ub[i]);  // x_0 = x0 is box-constrained too (:56,:58)
 
+    // warm start is per instance: only iterates of a solve that ended "optimal" are reused (the flag lives in the spare
+    // part of the kf block); an instance that was infeasible / hit the limit last time starts cold
+    double* okflag = g.ws + 2L * N * W * bt + (long)N * MC * bt;
+    const bool lane_warm = g.warm && okflag[ii] == 1.0;
     for (int k = 0; k < N; ++k) {
 #pragma unroll
         for (int i = 0; i < W; ++i) {
-            y[((long)k * W + i) * bt + ii] = 0.0;
-            lam[((long)k * W + i) * bt + ii] = 0.0;
+            if (!lane_warm) {
+                y[((long)k * W + i) * bt + ii] = 0.0;
+                lam[((long)k * W + i) * bt + ii] = 0.0;
+            } else if (g.warm == 2 && k + 1 < N) {   // receding horizon: the old plan advanced by one step (tail repeated)
+                y[((long)k * W + i) * bt + ii] = y[((long)(k + 1) * W + i) * bt + ii];
+                lam[((long)k * W + i) * bt + ii] = lam[((long)(k + 1) * W + i) * bt + ii];
+            }
             rv[((long)k * W + i) * bt + ii] = 0.0;
         }
 #pragma unroll
@@ -354,6 +364,7 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const double* __restrict_
             }
         }
         g.status[ii] = status ? status : ZM_MPC_USER_LIMIT;
+        okflag[ii] = (status == ZM_MPC_OPTIMAL) ? 1.0 : 0.0;
         if (g.iters) g.iters[ii] = it;
         if (g.resid) {
             g.resid[ii * 2] = rp;
@@ -392,12 +403,22 @@ extern "C" int zm_mpc_solve_f64(const double* A, const double* B, const double* 
                                 const double* x0, double rho, double eps_abs, double eps_rel, double eps_prim_inf,
                                 int max_iter, double* workspace, double* xTraj, double* uTraj, int32_t* status, int32_t* iters,
                                 double* resid, int64_t batch, int N, int n, int m, void* stream) {
+    return zm_mpc_solve_warm_f64(A, B, K, Minv, x_lb, x_ub, u_lb, u_ub, x0, rho, eps_abs, eps_rel, eps_prim_inf, max_iter, 0,
+                                 workspace, xTraj, uTraj, status, iters, resid, batch, N, n, m, stream);
+}
+
+extern "C" int zm_mpc_solve_warm_f64(const double* A, const double* B, const double* K, const double* Minv,
+                                     const double* x_lb, const double* x_ub, const double* u_lb, const double* u_ub,
+                                     const double* x0, double rho, double eps_abs, double eps_rel, double eps_prim_inf,
+                                     int max_iter, int warm_start, double* workspace, double* xTraj, double* uTraj,
+                                     int32_t* status, int32_t* iters, double* resid, int64_t batch, int N, int n, int m,
+                                     void* stream) {
     if (!A || !B || !K || !Minv || !x_lb || !x_ub || !u_lb || !u_ub || !x0 || !workspace || !xTraj || !uTraj || !status)
         return zm::set_error(ZM_EINVAL, "zm_mpc_solve_f64: null pointer");
     if (batch < 0 || N < 1 || max_iter < 0 || !(rho > 0.0)) return zm::set_error(ZM_EINVAL, "zm_mpc_solve_f64: bad size");
     if (batch == 0) return ZM_OK;
     zm::MpcTabs t{A, B, K, Minv, x_lb, x_ub, u_lb, u_ub};
-    zm::MpcArgs g{x0, rho, eps_abs, eps_rel, eps_prim_inf, max_iter, workspace, xTraj, uTraj, (int*)status, (int*)iters, resid,
+    zm::MpcArgs g{x0, rho, eps_abs, eps_rel, eps_prim_inf, max_iter, warm_start == 2 ? 2 : (warm_start ? 1 : 0), workspace, xTraj, uTraj, (int*)status, (int*)iters, resid,
                   (long)batch, N};
     hipStream_t st = (hipStream_t)stream;
     if (n == 12 && m == 4) return zm::launch_mpc<12, 4>(t, g, st);

@@ -51,6 +51,7 @@ class lqrMpc():
             raise ValueError("inconsistent lqrMpc problem shapes")
         self._dev = None
         self._tables = {}
+        self._ws = None   # ((batch, device, rho), ADMM workspace) of the last solve: warm start
         # one penalty for every instance: the geometric mean of the cost curvatures keeps both blocks of the
         # w-update Hessian (2Q + rho I, 2R + rho I) comparably conditioned
         self.rho = float(np.sqrt(max(np.trace(2 * self.Q) / self.n, 1e-12) * max(np.trace(2 * self.R) / self.m, 1e-12)))
@@ -80,8 +81,11 @@ class lqrMpc():
             x0 : Initial state (n,) -- or (..., n): a batch of independent instances
             **kwargs : solver options, named as the OSQP options the reference forwards through cvxpy
                 (demos/lqrMpc.py:32): eps_abs, eps_rel (default 1e-5, cvxpy's OSQP default), max_iter (default 10000),
-                rho, eps_prim_inf (default 1e-4); `solver` may be None or "OSQP" (the build has one solver);
-                eps_dual_inf / verbose / warm_start / polish are accepted and ignored.
+                rho, eps_prim_inf (default 1e-4), warm_start (default True, as cvxpy: a solve for the same batch shape
+                starts from the previous solve's ADMM iterates; `warm_start="shift"` (extension) advances them by one
+                horizon step first, the right guess inside the receding-horizon loop of demos/lqrMpc.py:41-48);
+                `solver` may be None or "OSQP" (the build has one solver); eps_dual_inf / verbose / polish are accepted
+                and ignored.
 
         Returns
         -------
@@ -97,7 +101,10 @@ class lqrMpc():
         max_iter = int(kwargs.pop("max_iter", 10000))
         rho = float(kwargs.pop("rho", self.rho))
         eps_pinf = float(kwargs.pop("eps_prim_inf", 1e-4))
-        for k in ("eps_dual_inf", "verbose", "warm_start", "warm_starting", "polish", "polishing"):
+        warm = kwargs.pop("warm_start", kwargs.pop("warm_starting", True))
+        shift = isinstance(warm, str) and warm == "shift"     # extension: previous iterates advanced by one horizon step
+        warm = bool(warm)
+        for k in ("eps_dual_inf", "verbose", "polish", "polishing"):
             kwargs.pop(k, None)
         if kwargs:
             raise TypeError(f"unknown solver options {sorted(kwargs)}")
@@ -110,17 +117,22 @@ class lqrMpc():
         Bn = dx0.shape[0]
         dev = dx0.device
         N, n, m = self.N, self.n, self.m
-        ws = torch.empty(4 * Bn * N * (n + m), dtype=torch.float64, device=dev)
+        key = (Bn, str(dev), rho)
+        warm = warm and self._ws is not None and self._ws[0] == key
+        if not warm:
+            self._ws = (key, torch.empty(4 * Bn * N * (n + m), dtype=torch.float64, device=dev))
+        ws = self._ws[1]
         xT = torch.empty((Bn, N + 1, n), dtype=torch.float64, device=dev)
         uT = torch.empty((Bn, N, m), dtype=torch.float64, device=dev)
         st = torch.empty(Bn, dtype=torch.int32, device=dev)
         its = torch.empty(Bn, dtype=torch.int32, device=dev)
         res = torch.empty((Bn, 2), dtype=torch.float64, device=dev)
-        rc = _lib.lib().zm_mpc_solve_f64(d["A"].data_ptr(), d["B"].data_ptr(), K.data_ptr(), Mi.data_ptr(),
-                                         d["x_lb"].data_ptr(), d["x_ub"].data_ptr(), d["u_lb"].data_ptr(),
-                                         d["u_ub"].data_ptr(), dx0.data_ptr(), rho, eps_abs, eps_rel, eps_pinf, max_iter,
-                                         ws.data_ptr(), xT.data_ptr(), uT.data_ptr(), st.data_ptr(), its.data_ptr(),
-                                         res.data_ptr(), Bn, N, n, m, ctypes.c_void_p(arr.stream_ptr(dx0)))
+        rc = _lib.lib().zm_mpc_solve_warm_f64(d["A"].data_ptr(), d["B"].data_ptr(), K.data_ptr(), Mi.data_ptr(),
+                                              d["x_lb"].data_ptr(), d["x_ub"].data_ptr(), d["u_lb"].data_ptr(),
+                                              d["u_ub"].data_ptr(), dx0.data_ptr(), rho, eps_abs, eps_rel, eps_pinf,
+                                              max_iter, (2 if shift else 1) if warm else 0, ws.data_ptr(), xT.data_ptr(), uT.data_ptr(),
+                                              st.data_ptr(), its.data_ptr(), res.data_ptr(), Bn, N, n, m,
+                                              ctypes.c_void_p(arr.stream_ptr(dx0)))
         _lib.check(rc, "lqrMpc.solve")
         self.last_iterations = its.reshape(lead).cpu().numpy()
         self.last_residuals = res.reshape(lead + (2,)).cpu().numpy()
