@@ -36,7 +36,8 @@ int zm_version(void);
 /* Thread-local description of the last error returned on this thread ("" if none). */
 const char* zm_last_error(void);
 
-/* 1 if (n, m) is covered by the compiled kernels for the given element size (8 = fp64), else 0. */
+/* 1 if (n, m) is covered by the compiled LQR sweep kernels for the given element size (8 = fp64: tile-16 MFMA kernels
+ * for n <= 12, m <= 4, LDS coverage kernel up to n <= 64, m <= 16; 4 = fp32: zm_lqr_backward_f32), else 0. */
 int zm_lqr_backward_supported(int n, int m, int elem_size);
 
 /* Batched discrete finite-horizon LQR backward Riccati recursion (Joseph-form value update).

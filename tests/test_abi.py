@@ -34,7 +34,9 @@ def test_version_and_support_matrix():
     assert lib.zm_lqr_backward_supported(12, 4, 8) == 1
     assert lib.zm_lqr_backward_supported(4, 1, 8) == 1
     assert lib.zm_lqr_backward_supported(8, 4, 8) == 1
-    assert lib.zm_lqr_backward_supported(64, 16, 4) == 0   # config 5 (tiled fp32 kernel) not built yet
+    assert lib.zm_lqr_backward_supported(64, 16, 4) == 1   # config 5: tiled fp32 MFMA kernel
+    assert lib.zm_lqr_backward_supported(64, 16, 8) == 1   # fp64 LDS coverage kernel
+    assert lib.zm_lqr_backward_supported(65, 16, 8) == 0 and lib.zm_lqr_backward_supported(12, 17, 4) == 0
     assert lib.zm_lqr_backward_supported(0, 1, 8) == 0
 
 
@@ -44,7 +46,7 @@ def test_bad_arguments_return_codes_without_gpu():
     assert rc == _lib.ZM_EINVAL
     assert b"null" in lib.zm_last_error()
     dummy = 0x1000
-    rc = lib.zm_lqr_backward_f64(dummy, dummy, dummy, dummy, dummy, 1, 5, 64, 16, None)
+    rc = lib.zm_lqr_backward_f64(dummy, dummy, dummy, dummy, dummy, 1, 5, 65, 16, None)
     assert rc == _lib.ZM_EUNSUPPORTED
     rc = lib.zm_lqr_backward_f64(dummy, dummy, dummy, dummy, dummy, -1, 5, 2, 2, None)
     assert rc == _lib.ZM_EINVAL

@@ -162,6 +162,6 @@ def test_host_pointer_entry_point(lqr):
 
 
 def test_unsupported_shape_raises_valueerror(lqr):
-    A, B, Q, R = problems.random_time_varying(1, 3, 16, 5, seed=2)
+    A, B, Q, R = problems.random_time_varying(1, 3, 65, 5, seed=2)      # beyond n <= 64, m <= 16
     with pytest.raises(ValueError):
         lqr.discreteFiniteHorizonLqr(A, B, Q, R, 3)

@@ -114,6 +114,29 @@ def test_unsupported_shapes_raise(lqr):
     A, B, Q, R = problems.random_time_varying(1, 2, 65, 4, seed=1, dtype=np.float32)
     with pytest.raises(ValueError):
         lqr.discreteFiniteHorizonLqr(A, B, Q, R, 2)
-    A, B, Q, R = problems.random_time_varying(1, 2, 20, 4, seed=1, dtype=np.float64)     # fp64 beyond the tile-16 kernel
+    A, B, Q, R = problems.random_time_varying(1, 2, 20, 17, seed=1, dtype=np.float64)
     with pytest.raises(ValueError):
         lqr.discreteFiniteHorizonLqr(A, B, Q, R, 2)
+
+
+@pytest.mark.parametrize("n,m,T,batch", [(64, 16, 6, 3), (20, 4, 9, 2), (13, 1, 5, 2), (12, 5, 7, 3), (33, 7, 4, 2), (3, 16, 3, 2),
+                                         (48, 12, 30, 2)])
+def test_fp64_beyond_tile16_lds_kernel(lqr, n, m, T, batch):
+    """fp64 inputs outside n <= 12, m <= 4 run the LDS coverage kernel (same formulas, reference operation order): 1e-10."""
+    A, B, Q, R = problems.random_time_varying(batch, T, n, m, seed=50 + n + m, dtype=np.float64)
+    Lg = lqr.discreteFiniteHorizonLqr(A, B, Q, R, T)
+    Lr = zo.discreteFiniteHorizonLqr(A, B, Q, R, T)
+    assert Lg.dtype == np.float64 and Lg.shape == (batch, T, m, n)
+    assert np.max(np.abs(Lg - Lr)) <= 1e-10 * np.max(np.abs(Lr))
+
+
+def test_fp64_lds_kernel_pivoting_and_nonsymmetric(lqr):
+    rng = np.random.default_rng(12)
+    n, m, T, batch = 24, 8, 4, 3
+    A, B, Q, _ = problems.random_time_varying(batch, T, n, m, seed=12, dtype=np.float64)
+    B *= 0.02
+    Q = Q + 0.2 * rng.standard_normal(Q.shape)                          # nonsymmetric Q (and hence V)
+    R = np.roll(np.eye(m), 1, axis=1)[None, None] + 0.01 * rng.standard_normal((batch, T, m, m))
+    Lg = lqr.discreteFiniteHorizonLqr(A, B, Q, R, T)
+    Lr = zo.discreteFiniteHorizonLqr(A, B, Q, R, T)
+    assert np.max(np.abs(Lg - Lr)) <= 1e-10 * np.max(np.abs(Lr))

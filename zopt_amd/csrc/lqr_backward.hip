@@ -187,8 +187,14 @@ int lqr_backward_dma_dispatch(const double* A, const double* B, const double* Q,
 
 }  // namespace zm
 
+namespace zm {
+int lqr_backward_lds_dispatch(const double* A, const double* B, const double* Q, const double* R, double* L, int64_t batch,
+                              int T, int n, int m, hipStream_t st);   // lqr_backward_lds_f64.hip
+}
+
 extern "C" int zm_lqr_backward_supported(int n, int m, int elem_size) {
-    return (elem_size == 8 && n >= 1 && n <= 12 && m >= 1 && m <= 4) ? 1 : 0;
+    if (n < 1 || m < 1 || n > 64 || m > 16) return 0;
+    return (elem_size == 8 || elem_size == 4) ? 1 : 0;
 }
 
 extern "C" int zm_lqr_backward_f64(const double* A, const double* B, const double* Q, const double* R, double* L,
@@ -198,11 +204,12 @@ extern "C" int zm_lqr_backward_f64(const double* A, const double* B, const doubl
         return zm::set_error(ZM_EINVAL, "zm_lqr_backward_f64: bad size batch=%lld T=%d n=%d m=%d", (long long)batch, T,
                              n, m);
     if (!zm_lqr_backward_supported(n, m, 8))
-        return zm::set_error(ZM_EUNSUPPORTED, "zm_lqr_backward_f64: (n=%d, m=%d) not covered (need n<=12, m<=4)", n, m);
+        return zm::set_error(ZM_EUNSUPPORTED, "zm_lqr_backward_f64: (n=%d, m=%d) not covered (need n<=64, m<=16)", n, m);
     if ((int64_t)T * n * n >= (int64_t)1 << 31 || batch >= ((int64_t)1 << 31))
         return zm::set_error(ZM_EUNSUPPORTED, "zm_lqr_backward_f64: T*n*n or batch too large");
     if (batch == 0) return ZM_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (n > 12 || m > 4) return zm::lqr_backward_lds_dispatch(A, B, Q, R, L, batch, T, n, m, st);   // coverage kernel
     // ZOPT_AMD_LQR_PATH=reg forces the register-prefetch kernel (A/B measurements); default: LDS-DMA when eligible.
     static const bool force_reg = [] {
         const char* e = getenv("ZOPT_AMD_LQR_PATH");
