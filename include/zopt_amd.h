@@ -62,6 +62,15 @@ int zm_lqr_backward_affine_f64(const double* A, const double* B, const double* d
                                const double* H, const double* q, const double* r, double* L, double* l,
                                int64_t batch, int T, int n, int m, void* stream);
 
+/* Batched discrete-time infinite-horizon LQR (DARE) by Riccati value iteration from V = Q on registers.
+ * Replaces: zopt/lqrUtils.py:176-204 discreteInfiniteHorizonLqr (SciPy solve_discrete_are + one solve).
+ * in : A (batch,n,n)  B (batch,n,m)  Q (batch,n,n)  R (batch,m,m)   [device]; n <= 12, m <= 4
+ *      tol: stop when max|V' - V| <= tol * max|V'| (or at the rounding floor); max_iter: iteration cap
+ * out: L (batch,m,n) with u = -L x;  P (batch,n,n) or NULL: the value matrix;  iters (batch) or NULL
+ */
+int zm_dare_f64(const double* A, const double* B, const double* Q, const double* R, double* L, double* P, int32_t* iters,
+                int64_t batch, int n, int m, double tol, int max_iter, void* stream);
+
 /* fp32 batched finite-horizon LQR backward sweep for large states (n <= 64, m <= 16): fp32 MFMA tile kernel.
  * Replaces: zopt/lqrUtils.py:144-173 discreteFiniteHorizonLqr when JAX runs in its default fp32 mode (x64 disabled, quirk Q8);
  *           the "large-state stress" shape n=64, m=16, T=200 of BASELINE configs[4].

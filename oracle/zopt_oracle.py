@@ -567,3 +567,12 @@ def differentialDynamicProgramming(dynFun, f_torch, Q, R, Qf, x0, uGuess, maxIte
         it += 1
     out = (traj, policy.L, J, converged)
     return out + (it,) if return_iters else out
+
+
+def discreteInfiniteHorizonLqr(A, B, Q, R):
+    """lqrUtils.py:202-203 verbatim in meaning: V = scipy.linalg.solve_discrete_are(A, B, Q, R);
+    L = solve(R + B^T V B, B^T V A).  SciPy is the library the reference itself calls (pinned 1.16.2; 1.15.3 here)."""
+    import scipy.linalg as spl
+    A, B, Q, R = (np.asarray(x, dtype=np.float64) for x in (A, B, Q, R))
+    V = spl.solve_discrete_are(A, B, Q, R)
+    return np.linalg.solve(R + B.T @ V @ B, B.T @ V @ A), V

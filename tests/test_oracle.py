@@ -223,3 +223,11 @@ def test_kat_iterativeLqr_converges_to_riccati():
         x = x + u
     assert traj.xTraj[-1] == pytest.approx(x, abs=1e-9)
     assert L == pytest.approx(-K, abs=1e-9)
+
+
+def test_dare_oracle_known_answer():
+    """reference tests/test_lqrUtils.py:72-79 (the oracle is the same SciPy call the reference makes, lqrUtils.py:202-203)."""
+    I = np.eye(2)
+    L, V = zo.discreteInfiniteHorizonLqr(I, I, I, I)
+    assert L == pytest.approx((1 + np.sqrt(5)) / (3 + np.sqrt(5)) * np.eye(2))
+    assert V == pytest.approx((1 + np.sqrt(5)) / 2 * np.eye(2))

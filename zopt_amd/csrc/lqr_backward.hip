@@ -181,6 +181,110 @@ static int launch_t16(const double* A, const double* B, const double* Q, const d
     return ZM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// DARE by Riccati value iteration: the same step with time-invariant operands held in registers, repeated from V = Q
+// until the value matrix stops changing.  Replaces zopt/lqrUtils.py:176-204 discreteInfiniteHorizonLqr
+// (V = scipy.linalg.solve_discrete_are(A, B, Q, R); L = solve(R + B^T V B, B^T V A)): for a stabilisable / detectable
+// problem the recursion from V = Q >= 0 converges to that stabilising solution; the reference's own test uses the long
+// finite horizon as the cross-check of this function.  One wave per system, no HBM traffic inside the loop.
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = __builtin_fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+template <int KS>
+__global__ __launch_bounds__(64, 4) void dare_t16_f64(const double* __restrict__ A, const double* __restrict__ B,
+                                                      const double* __restrict__ Q, const double* __restrict__ R,
+                                                      double* __restrict__ L, double* __restrict__ P, int* __restrict__ iters,
+                                                      const long batch, const int n, const int m, const double tol,
+                                                      const int max_iter) {
+    constexpr int NP = 4 * KS;
+    const int lane = threadIdx.x & 63;
+    const long sys = blockIdx.x;
+    if (sys >= batch) return;
+    const int g = lane >> 4, c = lane & 15;
+    __shared__ double smw[64];
+
+    LqrAddr<KS> a;
+    a.nn = n * n;
+    a.nm = n * m;
+    a.mm = m * m;
+    const bool cA = c < n;
+    const bool cB = (c >= NP) && (c < NP + m);
+    const double* At = A + sys * a.nn;
+    const double* Bt = B + sys * a.nm;
+    const double* Qt = Q + sys * a.nn;
+    const double* Rt = R + sys * a.mm;
+    const bool row0 = g < n;
+    const bool laneA = row0 && cA, laneB = row0 && cB;
+    a.q4n = 4 * n;
+    a.dF = laneA ? 4 * n : laneB ? 4 * m : 0;
+    a.sF = 0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int row = 4 * s + g;
+        a.rowok[s] = row < n;
+        a.vF[s] = (row < n) && (cA || cB);
+        a.vQ[s] = (row < n) && cA;
+    }
+    a.pF0 = laneA ? (At + g * n + c) : laneB ? (Bt + g * m + (c - NP)) : At;
+    a.pQ0 = laneA ? (Qt + g * n + c) : Qt;
+    if (!laneA) a.q4n = 0;
+    a.vRm = (g < m) && cB;
+    a.pRm = a.vRm ? (Rt + g * m + (c - NP)) : Rt;
+    a.rm_pad = (g >= m && c == NP + g) ? 1.0 : 0.0;
+    a.vBt = cA && (g < m);
+    a.pBt = a.vBt ? (Bt + c * m + g) : Bt;
+    a.vRt = (c < m) && (g < m);
+    a.pRt = a.vRt ? (Rt + c * m + g) : Rt;
+    a.vL = (g < m) && cA;
+    a.nn = a.nm = a.mm = 0;   // time-invariant: lqr_load_step must not move the pointers
+    LqrStepRegs<KS> d;
+    lqr_load_step(d, a);
+    double V[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) V[s] = d.Qd[s];
+
+    double lv = 0.0, prev = 1e300;
+    int it = 0, stall = 0;
+    while (it < max_iter) {   // every quantity in the loop condition is wave-uniform
+        double Vo[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) Vo[s] = V[s];
+        lv = lqr_step_core<KS>(V, d, smw, g, c, a.vL, []() {});
+        ++it;
+        if ((it & 3) == 0 || it == max_iter) {
+            double df = 0.0, sc = 0.0;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                df = __builtin_fmax(df, __builtin_fabs(V[s] - Vo[s]));
+                sc = __builtin_fmax(sc, __builtin_fabs(V[s]));
+            }
+            df = wave_max(df);
+            sc = wave_max(sc);
+            if (!(df > tol * sc)) break;                           // converged (or NaN: stop)
+            stall = (df >= prev && df <= 1e-9 * sc) ? stall + 1 : 0;   // rounding floor reached
+            if (stall >= 3) break;
+            prev = df;
+        }
+    }
+    // gain of the converged value: one more solve with V fixed (lv above belongs to the previous iterate)
+    {
+        double Vc[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) Vc[s] = V[s];
+        lv = lqr_step_core<KS>(Vc, d, smw, g, c, a.vL, []() {});
+    }
+    if (a.vL) L[sys * (long)(n * m) + g * n + c] = lv;
+    if (P) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            if (4 * s + g < n && cA) P[sys * (long)(n * n) + (4 * s + g) * n + c] = V[s];
+    }
+    if (iters && lane == 0) iters[sys] = it;
+}
+
 // lqr_backward_dma.hip: LDS-DMA staged fast path (even n, m; 16-B aligned pointers); ZM_EUNSUPPORTED otherwise.
 int lqr_backward_dma_dispatch(const double* A, const double* B, const double* Q, const double* R, double* L,
                               int64_t batch, int T, int n, int m, hipStream_t stream);
@@ -225,4 +329,23 @@ extern "C" int zm_lqr_backward_f64(const double* A, const double* B, const doubl
     if (n <= 4) return zm::launch_t16<1, 0, 0>(A, B, Q, R, L, batch, T, n, m, st);
     if (n <= 8) return zm::launch_t16<2, 0, 0>(A, B, Q, R, L, batch, T, n, m, st);
     return zm::launch_t16<3, 0, 0>(A, B, Q, R, L, batch, T, n, m, st);
+}
+
+extern "C" int zm_dare_f64(const double* A, const double* B, const double* Q, const double* R, double* L, double* P,
+                           int32_t* iters, int64_t batch, int n, int m, double tol, int max_iter, void* stream) {
+    if (!A || !B || !Q || !R || !L) return zm::set_error(ZM_EINVAL, "zm_dare_f64: null pointer");
+    if (batch < 0 || n < 1 || m < 1 || max_iter < 1 || !(tol >= 0.0)) return zm::set_error(ZM_EINVAL, "zm_dare_f64: bad argument");
+    if (n > 12 || m > 4) return zm::set_error(ZM_EUNSUPPORTED, "zm_dare_f64: (n=%d, m=%d) not covered (need n<=12, m<=4)", n, m);
+    if (batch >= ((int64_t)1 << 31)) return zm::set_error(ZM_EUNSUPPORTED, "zm_dare_f64: batch too large");
+    if (batch == 0) return ZM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)batch), block(64);
+    if (n <= 4)
+        hipLaunchKernelGGL((zm::dare_t16_f64<1>), grid, block, 0, st, A, B, Q, R, L, P, (int*)iters, (long)batch, n, m, tol, max_iter);
+    else if (n <= 8)
+        hipLaunchKernelGGL((zm::dare_t16_f64<2>), grid, block, 0, st, A, B, Q, R, L, P, (int*)iters, (long)batch, n, m, tol, max_iter);
+    else
+        hipLaunchKernelGGL((zm::dare_t16_f64<3>), grid, block, 0, st, A, B, Q, R, L, P, (int*)iters, (long)batch, n, m, tol, max_iter);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
 }

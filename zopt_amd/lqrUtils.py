@@ -74,6 +74,50 @@ def discreteFiniteHorizonLqr(A, B, Q, R, N):
     return arr.result_like(dL, A)
 
 
+def discreteInfiniteHorizonLqr(A, B, Q, R, tol=1e-14, maxIter=200000, return_value=False):
+    """Discrete-time infinite-horizon LQR gains (reference lqrUtils.py:176-204: SciPy `solve_discrete_are` + one solve).
+
+    ```
+    J = sum_k(x^T Q x + u^T R u);   xNew = A x + B u;   uLqr = -L x
+    ```
+    Here: Riccati value iteration from V = Q on the GPU, one wave per system, until `max|V' - V| <= tol * max|V'|`.
+
+    Arguments
+    ---------
+        A : (..., n, n)    B : (..., n, m)    Q : (..., n, n)    R : (..., m, m)     (n <= 12, m <= 4)
+
+    Returns
+    -------
+        L : (..., m, n) optimal LQR gains `u = -L x`   (with `return_value=True`: (L, V, iterations))
+    """
+    shp = tuple(B.shape) if hasattr(B, "shape") else tuple(np.shape(B))
+    if len(shp) < 2:
+        _shape_error("B must have shape (..., n, m)")
+    n, m = shp[-2:]
+    lead = shp[:-2]
+    for name, X, tail in (("A", A, (n, n)), ("B", B, (n, m)), ("Q", Q, (n, n)), ("R", R, (m, m))):
+        s_ = tuple(X.shape) if hasattr(X, "shape") else tuple(np.shape(X))
+        if s_ != lead + tail:
+            _shape_error(f"{name} has shape {s_}, expected {lead + tail}")
+    dt = torch.float64
+    dA, dB, dQ, dR = [arr.to_device(X, dt) for X in (A, B, Q, R)]
+    batch = 1
+    for d in lead:
+        batch *= int(d)
+    dL = torch.empty(lead + (m, n), dtype=dt, device=dA.device)
+    dP = torch.empty(lead + (n, n), dtype=dt, device=dA.device)
+    its = torch.empty(lead, dtype=torch.int32, device=dA.device)
+    rc = _lib.lib().zm_dare_f64(dA.data_ptr(), dB.data_ptr(), dQ.data_ptr(), dR.data_ptr(), dL.data_ptr(), dP.data_ptr(),
+                                its.data_ptr(), batch, n, m, float(tol), int(maxIter), ctypes.c_void_p(arr.stream_ptr(dA)))
+    _lib.check(rc, "discreteInfiniteHorizonLqr")
+    fp32_in = (arr.is_torch(A) and A.dtype == torch.float32) or (not arr.is_torch(A) and np.asarray(A).dtype == np.float32)
+    if fp32_in:
+        dL, dP = dL.to(torch.float32), dP.to(torch.float32)
+    if return_value:
+        return arr.result_like(dL, A), arr.result_like(dP, A), arr.result_like(its, A)
+    return arr.result_like(dL, A)
+
+
 def bilinearAffineLqr(A, B, d, Q, R, H, q, r, q0, N):
     """Finite Horizon LQR with bilinear cost and affine dynamics (reference lqrUtils.py:207-262).
 
