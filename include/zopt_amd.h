@@ -108,6 +108,8 @@ typedef struct zm_model_t {
     double dt;              /* quadcopter: Euler step (demos/iterativeLqr.py:23,35) */
     const double* A;        /* linear: device pointers; else NULL */
     const double* B;
+    double wind_ned[3];     /* quadcopter: constant wind in the north-east-down frame (quadcopter.py:117,138; the closed-loop
+                               simulation of demos/iterativeLqr.py:48 uses (3,1,0)); zeros for the solvers */
 } zm_model_t;
 
 /* c(x,u) = x^T Q x + u^T R u,  c_f(x) = x^T Qf x  (demos/iterativeLqr.py:12-13,37; no 1/2).  Device pointers. */

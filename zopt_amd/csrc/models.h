@@ -89,17 +89,26 @@ __device__ __forceinline__ Hyper ztan(Hyper a) {
 
 // ---- quadcopter (zopt/quadcopter.py) ---------------------------------------------------------------------------
 // state [u,v,w,p,q,r,phi,theta,psi,x,y,z], control [thrust,mx,my,mz]; g = 9.807, mass = 2.5, I = eye(3) (:15-18).
-// Wind is zero (the iLQR / MPC demos roll out without wind: demos/iterativeLqr.py:35).
+// wind = constant wind in the NED frame (:117): the aero forces see uvw - R_b2i^T wind (:138, :64).  The iLQR / MPC demos
+// roll out without wind (demos/iterativeLqr.py:35); their closed-loop simulation uses (3,1,0) (:48).
 template <typename S>
-__device__ __forceinline__ void quad_inertial_dynamics(const S (&x)[12], const S (&u)[4], S (&xd)[12]) {
+__device__ __forceinline__ void quad_inertial_dynamics(const S (&x)[12], const S (&u)[4], const double (&wind)[3], S (&xd)[12]) {
     constexpr double g = 9.807, mass = 2.5;
     const S cphi = zcos(x[6]), sphi = zsin(x[6]);
     const S cth = zcos(x[7]), sth = zsin(x[7]), tth = ztan(x[7]);
     const S cpsi = zcos(x[8]), spsi = zsin(x[8]);
-    // _getAeroForceMomemnts (:51-67): force = lin * uvw + quad * uvw^2, moment = lin * pqr
-    const S fa0 = -0.2 * x[0] + -0.05 * (x[0] * x[0]);
-    const S fa1 = -0.2 * x[1] + -0.05 * (x[1] * x[1]);
-    const S fa2 = -0.3 * x[2] + -0.1 * (x[2] * x[2]);
+    // R_b2i as written in the reference (:31-37; [0][2] = cphi*sth*cpsi - sphi*spsi, quirk Q4)
+    const S r00 = cth * cpsi, r01 = sphi * sth * cpsi - cphi * spsi, r02 = cphi * sth * cpsi - sphi * spsi;
+    const S r10 = cth * spsi, r11 = sphi * sth * spsi + cphi * cpsi, r12 = cphi * sth * spsi - sphi * cpsi;
+    const S r20 = -sth, r21 = sphi * cth, r22 = cphi * cth;
+    // wind_body = R_b2i^T wind_ned (:138); body velocities wrt the air (:64)
+    const S va0 = x[0] - ((r00 * wind[0] + r10 * wind[1]) + r20 * wind[2]);
+    const S va1 = x[1] - ((r01 * wind[0] + r11 * wind[1]) + r21 * wind[2]);
+    const S va2 = x[2] - ((r02 * wind[0] + r12 * wind[1]) + r22 * wind[2]);
+    // _getAeroForceMomemnts (:51-67): force = lin * uvw_aero + quad * uvw_aero^2, moment = lin * pqr
+    const S fa0 = -0.2 * va0 + -0.05 * (va0 * va0);
+    const S fa1 = -0.2 * va1 + -0.05 * (va1 * va1);
+    const S fa2 = -0.3 * va2 + -0.1 * (va2 * va2);
     const S ma0 = -0.1 * x[3], ma1 = -0.1 * x[4], ma2 = -0.05 * x[5];
     // rigidBodyDynamics (:70-113)
     const S d2x = -sth, d2y = sphi * cth, d2z = cphi * cth;                       // :94
@@ -120,10 +129,10 @@ __device__ __forceinline__ void quad_inertial_dynamics(const S (&x)[12], const S
     xd[6] = (x[3] + (sphi * tth) * x[4]) + (cphi * tth) * x[5];
     xd[7] = cphi * x[4] - sphi * x[5];
     xd[8] = (sphi / cth) * x[4] + (cphi / cth) * x[5];
-    // xyzDot = R_b2i @ uvw, R_b2i as written in the reference (:31-37; [0][2] = cphi*sth*cpsi - sphi*spsi, quirk Q4)
-    xd[9] = ((cth * cpsi) * x[0] + (sphi * sth * cpsi - cphi * spsi) * x[1]) + (cphi * sth * cpsi - sphi * spsi) * x[2];
-    xd[10] = ((cth * spsi) * x[0] + (sphi * sth * spsi + cphi * cpsi) * x[1]) + (cphi * sth * spsi - sphi * cpsi) * x[2];
-    xd[11] = ((-sth) * x[0] + (sphi * cth) * x[1]) + (cphi * cth) * x[2];
+    // xyzDot = R_b2i @ uvw (:142)
+    xd[9] = (r00 * x[0] + r01 * x[1]) + r02 * x[2];
+    xd[10] = (r10 * x[0] + r11 * x[1]) + r12 * x[2];
+    xd[11] = (r20 * x[0] + r21 * x[1]) + r22 * x[2];
 }
 
 // One discrete step x+ = f(x, u) of a registered model.  n, m are the model's dimensions (<= MAXN, MAXM).
@@ -131,7 +140,7 @@ template <typename S>
 __device__ __forceinline__ void model_step(const zm_model_t& md, const S (&x)[MAXN], const S (&u)[MAXM], S (&xn)[MAXN]) {
     if (md.kind == ZM_MODEL_QUADCOPTER) {
         S xd[12];
-        quad_inertial_dynamics<S>(x, u, xd);
+        quad_inertial_dynamics<S>(x, u, md.wind_ned, xd);
 #pragma unroll
         for (int i = 0; i < 12; ++i) xn[i] = x[i] + md.dt * xd[i];
     } else {  // ZM_MODEL_LINEAR: A @ x + B @ u

@@ -169,7 +169,8 @@ extern "C" int zm_rollout_linesearch_f64(const zm_model_t* model, const zm_quadc
         const char* e = getenv("ZOPT_AMD_ROLLOUT_PATH");
         return e && e[0] == 'g';
     }();
-    if (!force_generic && n_alpha == 16 && md.n == 12 && md.m == 4 && cost && T >= 1)
+    const bool windy = md.wind_ned[0] != 0.0 || md.wind_ned[1] != 0.0 || md.wind_ned[2] != 0.0;   // fast path: still air only
+    if (!force_generic && !windy && n_alpha == 16 && md.n == 12 && md.m == 4 && cost && T >= 1)
         return zm::rollout_fast_dispatch(md, cs.Q, cs.R, cs.Qf, x0, l, L, xPrev, uPrev, alphas, act, xTraj, uTraj, J,
                                          (int*)alpha_idx, batch, T, st);
     if (n_alpha == 1) {

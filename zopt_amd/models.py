@@ -19,7 +19,7 @@ ZM_MODEL_QUADCOPTER = 2
 
 class zm_model_t(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("n", ctypes.c_int), ("m", ctypes.c_int), ("reserved", ctypes.c_int),
-                ("dt", ctypes.c_double), ("A", ctypes.c_void_p), ("B", ctypes.c_void_p)]
+                ("dt", ctypes.c_double), ("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("wind_ned", ctypes.c_double * 3)]
 
 
 class zm_quadcost_t(ctypes.Structure):
@@ -52,11 +52,15 @@ class QuadcopterEuler:
     n, m = 12, 4
     uTrim = np.array([9.807, 0.0, 0.0, 0.0])   # hover: thrust = g (quadcopter.py:15, tests/test_quadcopter.py:55-58)
 
-    def __init__(self, dt: float = 0.1):
+    def __init__(self, dt: float = 0.1, wind_ned=(0.0, 0.0, 0.0)):
+        """dt: Euler step; wind_ned: constant wind in the NED frame (quadcopter.py:117; demos/iterativeLqr.py:48)"""
         self.dt = float(dt)
+        self.wind_ned = tuple(float(w) for w in wind_ned)
+        if len(self.wind_ned) != 3:
+            raise ValueError("wind_ned must have 3 components")
 
     def c_struct(self):
-        return zm_model_t(ZM_MODEL_QUADCOPTER, 12, 4, 0, self.dt, None, None)
+        return zm_model_t(ZM_MODEL_QUADCOPTER, 12, 4, 0, self.dt, None, None, (ctypes.c_double * 3)(*self.wind_ned))
 
 
 class QuadraticCost:
