@@ -27,6 +27,8 @@
 // is not certified within max_iter reports "user_limit".
 #include "zm_common.h"
 
+#include <type_traits>
+
 namespace zm {
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -138,8 +140,11 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const double* __restrict_
                                                        const MpcArgs g) {
     constexpr int W = NS + MC;
     const long inst = (long)blockIdx.x * 64 + threadIdx.x;
-    const bool live = inst < g.batch;
-    const long ii = live ? inst : 0;
+    // Lanes beyond the batch leave at once: the sweeps below store unconditionally (no branch per store), so no lane may
+    // alias another instance's slots; the wave-level votes (__all / __any) only count the lanes that are still here.
+    if (inst >= g.batch) return;
+    constexpr bool live = true;
+    const long ii = inst;
     const long bt = g.batch;
     const int N = g.N;
     const double rho = g.rho;
@@ -183,21 +188,43 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const double* __restrict_
     for (int gi = 0; gi < g.max_iter; ++gi) {  // gi is wave-uniform
         if (__all(done)) break;
         const bool chk = ((gi + 1) % 25) == 0;  // infeasibility certificate on this iteration
-        // ---- backward affine sweep: p <- -rho z_N; Qu = -rho zu_k + B^T p; kf_k = Suu_k^-1 Qu; p <- hx_k + A^T p - K_k^T Qu
+        // ---- backward affine sweep.  Costate of x_{k+1}: p = -rho z(x_{k+1}) + (A^T p - K^T Qu)_{k+1};
+        //      Qu = -rho z(u_k) + B^T p;  kf_k = Suu_k^-1 Qu.  Stage k touches only block k of (y, lam) (its states are the copy
+        //      of x_{k+1}), and block k-1 is fetched while stage k computes: no load is predicated, no store is conditional
+        //      (a finished lane rewrites the values it read), so the loop has no branch and one memory latency
+        //      per stage is hidden behind ~500 FMAs.
         double p[NS];
-        {
-            const long o = (long)(N - 1) * W;
 #pragma unroll
-            for (int i = 0; i < NS; ++i) p[i] = -rho * (y[(o + i) * bt + ii] - lam[(o + i) * bt + ii]);
+        for (int i = 0; i < NS; ++i) p[i] = 0.0;
+        double yb[W], lb[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            const long e = ((long)(N - 1) * W + i) * bt + ii;
+            yb[i] = y[e];
+            lb[i] = lam[e];
         }
+#pragma unroll 1
         for (int k = N - 1; k >= 0; --k) {
             const double* Kk = Ktab + (long)k * MC * NS;
             const double* Mk = Mtab + (long)k * MC * MC;
+            double yq[W], lq[W], kfo[MC];
+            {
+                const int kp = k > 0 ? k - 1 : 0;
+#pragma unroll
+                for (int i = 0; i < W; ++i) {
+                    const long e = ((long)kp * W + i) * bt + ii;
+                    yq[i] = y[e];
+                    lq[i] = lam[e];
+                }
+#pragma unroll
+                for (int j = 0; j < MC; ++j) kfo[j] = kf[((long)k * MC + j) * bt + ii];
+            }
+#pragma unroll
+            for (int i = 0; i < NS; ++i) p[i] = __builtin_fma(-rho, yb[i] - lb[i], p[i]);
             double qu[MC];
 #pragma unroll
             for (int j = 0; j < MC; ++j) {
-                const long e = ((long)k * W + NS + j) * bt + ii;
-                double sacc = -rho * (y[e] - lam[e]);
+                double sacc = -rho * (yb[NS + j] - lb[NS + j]);
 #pragma unroll
                 for (int i = 0; i < NS; ++i) sacc = __builtin_fma(B[i * MC + j], p[i], sacc);
                 qu[j] = sacc;
@@ -207,16 +234,12 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const double* __restrict_
                 double sacc = 0.0;
 #pragma unroll
                 for (int l = 0; l < MC; ++l) sacc = __builtin_fma(Mk[j * MC + l], qu[l], sacc);
-                if (!done) kf[((long)k * MC + j) * bt + ii] = sacc;
+                kf[((long)k * MC + j) * bt + ii] = done ? kfo[j] : sacc;   // a finished lane keeps the kf of its last iterate
             }
             double pn[NS];
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 double sacc = 0.0;
-                if (k >= 1) {
-                    const long e = ((long)(k - 1) * W + i) * bt + ii;  // the copy of x_k lives in stage k-1
-                    sacc = -rho * (y[e] - lam[e]);
-                }
 #pragma unroll
                 for (int l = 0; l < NS; ++l) sacc = __builtin_fma(A[l * NS + i], p[l], sacc);
 #pragma unroll
@@ -225,57 +248,98 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const double* __restrict_
             }
 #pragma unroll
             for (int i = 0; i < NS; ++i) p[i] = pn[i];
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                yb[i] = yq[i];
+                lb[i] = lq[i];
+            }
         }
         // ---- forward rollout w, projection y, dual update lam, residual norms (and r = w - y, support function on chk)
         double x[NS];
 #pragma unroll
         for (int i = 0; i < NS; ++i) x[i] = x0[i];
         double nrp = 0.0, nrd = 0.0, nw = 0.0, ny = 0.0, nl = 0.0, sup = 0.0;
-        for (int k = 0; k < N; ++k) {
-            const double* Kk = Ktab + (long)k * MC * NS;
-            double u[MC], xn[NS];
-#pragma unroll
-            for (int j = 0; j < MC; ++j) {
-                double sacc = -kf[((long)k * MC + j) * bt + ii];
-#pragma unroll
-                for (int i = 0; i < NS; ++i) sacc = __builtin_fma(-Kk[j * NS + i], x[i], sacc);
-                u[j] = sacc;
-            }
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                double sacc = 0.0;
-#pragma unroll
-                for (int l = 0; l < NS; ++l) sacc = __builtin_fma(A[i * NS + l], x[l], sacc);
-#pragma unroll
-                for (int j = 0; j < MC; ++j) sacc = __builtin_fma(B[i * MC + j], u[j], sacc);
-                xn[i] = sacc;
-            }
+        auto forward = [&](auto chk_c) {
+            constexpr bool CHK = decltype(chk_c)::value;
+            double kfc[MC];
 #pragma unroll
             for (int i = 0; i < W; ++i) {
-                const double wv = (i < NS) ? xn[i < NS ? i : 0] : u[i >= NS ? i - NS : 0];
-                const double lo = (i < NS) ? x_lb[i < NS ? i : 0] : u_lb[i >= NS ? i - NS : 0];
-                const double hi = (i < NS) ? x_ub[i < NS ? i : 0] : u_ub[i >= NS ? i - NS : 0];
-                const long e = ((long)k * W + i) * bt + ii;
-                const double lold = lam[e], yold = y[e];
-                double yn = wv + lold;
-                yn = yn < lo ? lo : (yn > hi ? hi : yn);
-                const double r = wv - yn;
-                const double ln = lold + r;
-                if (!done) {
-                    y[e] = yn;
-                    lam[e] = ln;
-                    if (chk) rv[e] = r;
-                }
-                if (chk) sup += (r > 0.0) ? r * hi : ((r < 0.0) ? r * lo : 0.0);  // support function of the box at v = r
-                nrp = __builtin_fmax(nrp, __builtin_fabs(r));
-                nrd = __builtin_fmax(nrd, __builtin_fabs(yn - yold));
-                nw = __builtin_fmax(nw, __builtin_fabs(wv));
-                ny = __builtin_fmax(ny, __builtin_fabs(yn));
-                nl = __builtin_fmax(nl, __builtin_fabs(ln));
+                const long e = (long)i * bt + ii;
+                yb[i] = y[e];
+                lb[i] = lam[e];
             }
 #pragma unroll
-            for (int i = 0; i < NS; ++i) x[i] = xn[i];
-        }
+            for (int j = 0; j < MC; ++j) kfc[j] = kf[(long)j * bt + ii];
+#pragma unroll 1
+            for (int k = 0; k < N; ++k) {
+                const double* Kk = Ktab + (long)k * MC * NS;
+                double yq[W], lq[W], kfq[MC];
+                {
+                    const int kn = k + 1 < N ? k + 1 : N - 1;
+#pragma unroll
+                    for (int i = 0; i < W; ++i) {
+                        const long e = ((long)kn * W + i) * bt + ii;
+                        yq[i] = y[e];
+                        lq[i] = lam[e];
+                    }
+#pragma unroll
+                    for (int j = 0; j < MC; ++j) kfq[j] = kf[((long)kn * MC + j) * bt + ii];
+                }
+                double u[MC], xn[NS];
+#pragma unroll
+                for (int j = 0; j < MC; ++j) {
+                    double sacc = -kfc[j];
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) sacc = __builtin_fma(-Kk[j * NS + i], x[i], sacc);
+                    u[j] = sacc;
+                }
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int l = 0; l < NS; ++l) sacc = __builtin_fma(A[i * NS + l], x[l], sacc);
+#pragma unroll
+                    for (int j = 0; j < MC; ++j) sacc = __builtin_fma(B[i * MC + j], u[j], sacc);
+                    xn[i] = sacc;
+                }
+#pragma unroll
+                for (int i = 0; i < W; ++i) {
+                    const double wv = (i < NS) ? xn[i < NS ? i : 0] : u[i >= NS ? i - NS : 0];
+                    const double lo = (i < NS) ? x_lb[i < NS ? i : 0] : u_lb[i >= NS ? i - NS : 0];
+                    const double hi = (i < NS) ? x_ub[i < NS ? i : 0] : u_ub[i >= NS ? i - NS : 0];
+                    const long e = ((long)k * W + i) * bt + ii;
+                    const double lold = lb[i], yold = yb[i];
+                    double yn = wv + lold;
+                    yn = yn < lo ? lo : (yn > hi ? hi : yn);
+                    const double r = wv - yn;
+                    const double ln = lold + r;
+                    y[e] = done ? yold : yn;       // a finished lane keeps its iterate
+                    lam[e] = done ? lold : ln;
+                    if constexpr (CHK) {
+                        rv[e] = r;                 // only read back by lanes that are not finished
+                        sup += (r > 0.0) ? r * hi : ((r < 0.0) ? r * lo : 0.0);  // support function of the box at v = r
+                    }
+                    nrp = __builtin_fmax(nrp, __builtin_fabs(r));
+                    nrd = __builtin_fmax(nrd, __builtin_fabs(yn - yold));
+                    nw = __builtin_fmax(nw, __builtin_fabs(wv));
+                    ny = __builtin_fmax(ny, __builtin_fabs(yn));
+                    nl = __builtin_fmax(nl, __builtin_fabs(ln));
+                }
+#pragma unroll
+                for (int i = 0; i < NS; ++i) x[i] = xn[i];
+#pragma unroll
+                for (int i = 0; i < W; ++i) {
+                    yb[i] = yq[i];
+                    lb[i] = lq[i];
+                }
+#pragma unroll
+                for (int j = 0; j < MC; ++j) kfc[j] = kfq[j];
+            }
+        };
+        if (chk)
+            forward(std::true_type{});
+        else
+            forward(std::false_type{});
         bool need_cert = false;
         if (!done) {
             ++it;
