@@ -134,6 +134,14 @@ int zm_rollout_linesearch_f64(const zm_model_t* model, const zm_quadcost_t* cost
                               int n_alpha, const int32_t* active, double* xTraj, double* uTraj, double* J,
                               int32_t* alpha_idx, int64_t batch, int T, void* stream);
 
+/* Same, over a compacted list of trajectory ids: only list[0..count) are processed (densely packed into waves), all
+ * other trajectories keep their outputs.  Arrays keep their full (batch, ...) shapes and are indexed by trajectory id.
+ * Used by the iLQR / DDP drivers once most of the batch has converged (a mask would leave mostly idle waves). */
+int zm_rollout_linesearch_list_f64(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0, const double* l,
+                                   const double* L, const double* xPrev, const double* uPrev, const double* alphas,
+                                   int n_alpha, const int32_t* list, int64_t count, double* xTraj, double* uTraj, double* J,
+                                   int32_t* alpha_idx, int64_t batch, int T, void* stream);
+
 /* First-order expansion of a registered model along a trajectory.
  * Replaces: zopt/pytrees.py:139-153 AffineDynamics.from_function / from_trajectory (jax.jacobian of dynFun at
  *           (xTraj[:-1], uTraj)):  f = dynFun(x_k,u_k), f_x = d dynFun/dx, f_u = d dynFun/du.

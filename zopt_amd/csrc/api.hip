@@ -35,6 +35,7 @@ extern "C" const char* zm_last_error(void) { return zm::last_error_buf(); }
 
 extern "C" int zm_lqr_backward_host_f64(const double* A, const double* B, const double* Q, const double* R, double* L,
                                         int64_t batch, int T, int n, int m) {
+    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     if (!A || !B || !Q || !R || !L) return zm::set_error(ZM_EINVAL, "zm_lqr_backward_host_f64: null pointer");
     if (batch < 0 || T < 1 || n < 1 || m < 1) return zm::set_error(ZM_EINVAL, "zm_lqr_backward_host_f64: bad size");
     if (!zm_lqr_backward_supported(n, m, 8))

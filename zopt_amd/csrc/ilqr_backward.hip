@@ -436,6 +436,7 @@ extern "C" int zm_ilqr_backward_ex_f64(const double* f_x, const double* f_u, con
                                        const double* c_xx, const double* c_ux, const double* c_uu, const double* vf_x,
                                        const double* vf_xx, const int32_t* active, int shared_hessian, double* l,
                                        double* L, int64_t batch, int T, int n, int m, void* stream) {
+    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     if (!f_x || !f_u || !c_x || !c_u || !c_xx || !c_ux || !c_uu || !vf_x || !vf_xx || !l || !L)
         return zm::set_error(ZM_EINVAL, "zm_ilqr_backward_f64: null pointer");
     const int rc = zm_check_sweep_args("zm_ilqr_backward_f64", batch, T, n, m);
@@ -449,6 +450,7 @@ extern "C" int zm_ilqr_backward_f64(const double* f_x, const double* f_u, const 
                                     const double* c_xx, const double* c_ux, const double* c_uu, const double* vf_x,
                                     const double* vf_xx, double* l, double* L, int64_t batch, int T, int n, int m,
                                     void* stream) {
+    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     return zm_ilqr_backward_ex_f64(f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, 0, l, L, batch, T, n, m,
                                    stream);
 }
@@ -456,6 +458,7 @@ extern "C" int zm_ilqr_backward_f64(const double* f_x, const double* f_u, const 
 extern "C" int zm_lqr_backward_affine_f64(const double* A, const double* B, const double* d, const double* Q,
                                           const double* R, const double* H, const double* q, const double* r, double* L,
                                           double* l, int64_t batch, int T, int n, int m, void* stream) {
+    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     if (!A || !B || !d || !Q || !R || !H || !q || !r || !L || !l)
         return zm::set_error(ZM_EINVAL, "zm_lqr_backward_affine_f64: null pointer");
     const int rc = zm_check_sweep_args("zm_lqr_backward_affine_f64", batch, T, n, m);
@@ -473,6 +476,7 @@ extern "C" int zm_ddp_backward_f64(const double* f_x, const double* f_u, const d
                                    const double* c_ux, const double* c_uu, const double* vf_x, const double* vf_xx,
                                    const int32_t* active, int shared_hessian, double* l, double* L, int64_t batch, int T,
                                    int n, int m, void* stream) {
+    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     if (!f_x || !f_u || !f_xx || !f_ux || !f_uu || !c_x || !c_u || !c_xx || !c_ux || !c_uu || !vf_x || !vf_xx || !l || !L)
         return zm::set_error(ZM_EINVAL, "zm_ddp_backward_f64: null pointer");
     const int rc = zm_check_sweep_args("zm_ddp_backward_f64", batch, T, n, m);

@@ -197,6 +197,7 @@ static int zm_check_model(const zm_model_t* model, zm_model_t& md, const char* w
 extern "C" int zm_linearize_dynamics_f64(const zm_model_t* model, const double* xTraj, const double* uTraj,
                                          const int32_t* active, double* f, double* f_x, double* f_u, int64_t batch, int T,
                                          void* stream) {
+    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     zm_model_t md;
     int rc = zm_check_model(model, md, "zm_linearize_dynamics_f64");
     if (rc) return rc;
@@ -214,6 +215,7 @@ extern "C" int zm_quadratize_cost_f64(const zm_quadcost_t* cost, int n, int m, c
                                       const int32_t* active, double* c, double* c_x, double* c_u, double* v, double* v_x,
                                       double* c_xx, double* c_ux, double* c_uu, double* v_xx, int64_t batch, int T,
                                       void* stream) {
+    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     if (!cost || !cost->Q || !cost->R || !cost->Qf || !xTraj || !uTraj)
         return zm::set_error(ZM_EINVAL, "zm_quadratize_cost_f64: null pointer");
     if (n < 1 || n > zm::MAXN || m < 1 || m > zm::MAXM)
@@ -234,6 +236,7 @@ extern "C" int zm_quadratize_cost_f64(const zm_quadcost_t* cost, int n, int m, c
 extern "C" int zm_quadratic_dynamics_f64(const zm_model_t* model, const double* xTraj, const double* uTraj,
                                          const int32_t* active, double* f_xx, double* f_ux, double* f_uu, int64_t batch,
                                          int T, void* stream) {
+    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     zm_model_t md;
     int rc = zm_check_model(model, md, "zm_quadratic_dynamics_f64");
     if (rc) return rc;

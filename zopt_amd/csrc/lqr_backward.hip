@@ -303,6 +303,7 @@ extern "C" int zm_lqr_backward_supported(int n, int m, int elem_size) {
 
 extern "C" int zm_lqr_backward_f64(const double* A, const double* B, const double* Q, const double* R, double* L,
                                    int64_t batch, int T, int n, int m, void* stream) {
+    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     if (!A || !B || !Q || !R || !L) return zm::set_error(ZM_EINVAL, "zm_lqr_backward_f64: null pointer");
     if (batch < 0 || T < 1 || n < 1 || m < 1)
         return zm::set_error(ZM_EINVAL, "zm_lqr_backward_f64: bad size batch=%lld T=%d n=%d m=%d", (long long)batch, T,
@@ -333,6 +334,7 @@ extern "C" int zm_lqr_backward_f64(const double* A, const double* B, const doubl
 
 extern "C" int zm_dare_f64(const double* A, const double* B, const double* Q, const double* R, double* L, double* P,
                            int32_t* iters, int64_t batch, int n, int m, double tol, int max_iter, void* stream) {
+    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     if (!A || !B || !Q || !R || !L) return zm::set_error(ZM_EINVAL, "zm_dare_f64: null pointer");
     if (batch < 0 || n < 1 || m < 1 || max_iter < 1 || !(tol >= 0.0)) return zm::set_error(ZM_EINVAL, "zm_dare_f64: bad argument");
     if (n > 12 || m > 4) return zm::set_error(ZM_EUNSUPPORTED, "zm_dare_f64: (n=%d, m=%d) not covered (need n<=12, m<=4)", n, m);

@@ -354,6 +354,7 @@ static int launch_tiled(const float* A, const float* B, const float* Q, const fl
 
 extern "C" int zm_lqr_backward_f32(const float* A, const float* B, const float* Q, const float* R, float* L, int64_t batch,
                                    int T, int n, int m, void* stream) {
+    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     if (!A || !B || !Q || !R || !L) return zm::set_error(ZM_EINVAL, "zm_lqr_backward_f32: null pointer");
     if (batch < 0 || T < 0 || n < 1 || m < 1) return zm::set_error(ZM_EINVAL, "zm_lqr_backward_f32: bad size");
     if (n > 64 || m > 16)

@@ -467,6 +467,7 @@ extern "C" int zm_mpc_solve_f64(const double* A, const double* B, const double* 
                                 const double* x0, double rho, double eps_abs, double eps_rel, double eps_prim_inf,
                                 int max_iter, double* workspace, double* xTraj, double* uTraj, int32_t* status, int32_t* iters,
                                 double* resid, int64_t batch, int N, int n, int m, void* stream) {
+    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     return zm_mpc_solve_warm_f64(A, B, K, Minv, x_lb, x_ub, u_lb, u_ub, x0, rho, eps_abs, eps_rel, eps_prim_inf, max_iter, 0,
                                  workspace, xTraj, uTraj, status, iters, resid, batch, N, n, m, stream);
 }
@@ -477,6 +478,7 @@ extern "C" int zm_mpc_solve_warm_f64(const double* A, const double* B, const dou
                                      int max_iter, int warm_start, double* workspace, double* xTraj, double* uTraj,
                                      int32_t* status, int32_t* iters, double* resid, int64_t batch, int N, int n, int m,
                                      void* stream) {
+    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     if (!A || !B || !K || !Minv || !x_lb || !x_ub || !u_lb || !u_ub || !x0 || !workspace || !xTraj || !uTraj || !status)
         return zm::set_error(ZM_EINVAL, "zm_mpc_solve_f64: null pointer");
     if (batch < 0 || N < 1 || max_iter < 0 || !(rho > 0.0)) return zm::set_error(ZM_EINVAL, "zm_mpc_solve_f64: bad size");

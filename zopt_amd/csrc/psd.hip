@@ -62,6 +62,7 @@ __global__ __launch_bounds__(64) void psd_project_kernel(const Mat M, const int 
 }  // namespace zm
 
 extern "C" int zm_psd_project_f64(double* A, int64_t count, int k, double eps, void* stream) {
+    if (count == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     if (!A) return zm::set_error(ZM_EINVAL, "zm_psd_project_f64: null pointer");
     if (count < 0 || k < 1) return zm::set_error(ZM_EINVAL, "zm_psd_project_f64: bad size");
     if (k > zm::PK) return zm::set_error(ZM_EUNSUPPORTED, "zm_psd_project_f64: k=%d > 16", k);
@@ -74,6 +75,7 @@ extern "C" int zm_psd_project_f64(double* A, int64_t count, int k, double eps, v
 
 extern "C" int zm_condition_cost_f64(double* c_xx, double* c_ux, double* c_uu, int64_t count, int n, int m, double eps,
                                      void* stream) {
+    if (count == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     if (!c_xx || !c_ux || !c_uu) return zm::set_error(ZM_EINVAL, "zm_condition_cost_f64: null pointer");
     if (count < 0 || n < 1 || m < 1) return zm::set_error(ZM_EINVAL, "zm_condition_cost_f64: bad size");
     if (n + m > zm::PK) return zm::set_error(ZM_EUNSUPPORTED, "zm_condition_cost_f64: n+m=%d > 16", n + m);

@@ -76,14 +76,17 @@ __global__ __launch_bounds__(64) void rollout_linesearch_kernel(const zm_model_t
                                                                 const double* __restrict__ xPrev,
                                                                 const double* __restrict__ uPrev,
                                                                 const double* __restrict__ alphas, const int n_alpha,
-                                                                const int* __restrict__ active, double* __restrict__ xTraj,
+                                                                const int* __restrict__ active, const int* __restrict__ list,
+                                                                const long count, double* __restrict__ xTraj,
                                                                 double* __restrict__ uTraj, double* __restrict__ Jout,
                                                                 int* __restrict__ idx_out, const long batch, const int T) {
     constexpr int TPW = 64 / NA;  // trajectories per wave
     const int lane = threadIdx.x;
     const int a = lane % NA;
-    const long traj = (long)blockIdx.x * TPW + lane / NA;
-    const bool live = (traj < batch) && (a < n_alpha) && (active == nullptr || active[traj < batch ? traj : 0] != 0);
+    const long slot = (long)blockIdx.x * TPW + lane / NA;   // slot -> trajectory id (through `list` when given)
+    const long nslot = list ? count : batch;
+    const long traj = (slot < nslot) ? (list ? (long)list[slot] : slot) : 0;
+    const bool live = (slot < nslot) && (a < n_alpha) && (active == nullptr || active[traj] != 0);
     const long t = live ? traj : 0;
     const int n = md.n, m = md.m;
     const zm_quadcost_t* cs = has_cost ? &cost : nullptr;
@@ -131,16 +134,16 @@ __global__ __launch_bounds__(64) void rollout_linesearch_kernel(const zm_model_t
 // rollout_fast.hip: compile-time (n, m) = (12, 4), 16 step sizes
 int rollout_fast_dispatch(const zm_model_t& md, const double* Q, const double* R, const double* Qf, const double* x0,
                           const double* l, const double* L, const double* xPrev, const double* uPrev,
-                          const double* alphas, const int* active, double* xTraj, double* uTraj, double* J, int* idx,
-                          int64_t batch, int T, hipStream_t st);
+                          const double* alphas, const int* active, const int* list, int64_t count, double* xTraj,
+                          double* uTraj, double* J, int* idx, int64_t batch, int T, hipStream_t st);
 
 }  // namespace zm
 
-extern "C" int zm_rollout_linesearch_f64(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0,
+static int rollout_impl(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0,
                                          const double* l, const double* L, const double* xPrev, const double* uPrev,
-                                         const double* alphas, int n_alpha, const int32_t* active, double* xTraj,
-                                         double* uTraj, double* J, int32_t* alpha_idx, int64_t batch, int T,
-                                         void* stream) {
+                                         const double* alphas, int n_alpha, const int32_t* active, const int32_t* list,
+                                         int64_t count, double* xTraj, double* uTraj, double* J, int32_t* alpha_idx,
+                                         int64_t batch, int T, void* stream) {
     if (!model || !x0 || !l || !L || !xPrev || !uPrev || !alphas || !xTraj || !uTraj)
         return zm::set_error(ZM_EINVAL, "zm_rollout_linesearch_f64: null pointer");
     if (batch < 0 || T < 0 || n_alpha < 1 || n_alpha > 16)
@@ -160,7 +163,9 @@ extern "C" int zm_rollout_linesearch_f64(const zm_model_t* model, const zm_quadc
         return zm::set_error(ZM_EUNSUPPORTED, "zm_rollout_linesearch_f64: (n=%d, m=%d) not covered (n<=12, m<=4)", md.n, md.m);
     if (cost && (!cost->Q || !cost->R || !cost->Qf))
         return zm::set_error(ZM_EINVAL, "zm_rollout_linesearch_f64: cost needs Q, R, Qf");
-    if (batch == 0) return ZM_OK;
+    if (batch == 0 || (list && count == 0)) return ZM_OK;
+    if (count < 0 || count > batch) return zm::set_error(ZM_EINVAL, "zm_rollout_linesearch: bad list length");
+    const int64_t nslot = list ? count : batch;
     hipStream_t st = (hipStream_t)stream;
     zm_quadcost_t cs = cost ? *cost : zm_quadcost_t{nullptr, nullptr, nullptr};
     const bool hc = cost != nullptr;
@@ -171,17 +176,37 @@ extern "C" int zm_rollout_linesearch_f64(const zm_model_t* model, const zm_quadc
     }();
     const bool windy = md.wind_ned[0] != 0.0 || md.wind_ned[1] != 0.0 || md.wind_ned[2] != 0.0;   // fast path: still air only
     if (!force_generic && !windy && n_alpha == 16 && md.n == 12 && md.m == 4 && cost && T >= 1)
-        return zm::rollout_fast_dispatch(md, cs.Q, cs.R, cs.Qf, x0, l, L, xPrev, uPrev, alphas, act, xTraj, uTraj, J,
-                                         (int*)alpha_idx, batch, T, st);
+        return zm::rollout_fast_dispatch(md, cs.Q, cs.R, cs.Qf, x0, l, L, xPrev, uPrev, alphas, act, (const int*)list, count, xTraj,
+                                         uTraj, J, (int*)alpha_idx, batch, T, st);
     if (n_alpha == 1) {
-        const unsigned blocks = (unsigned)((batch + 63) / 64);
+        const unsigned blocks = (unsigned)((nslot + 63) / 64);
         hipLaunchKernelGGL((zm::rollout_linesearch_kernel<1>), dim3(blocks), dim3(64), 0, st, md, cs, hc, x0, l, L, xPrev,
-                           uPrev, alphas, n_alpha, act, xTraj, uTraj, J, (int*)alpha_idx, (long)batch, T);
+                           uPrev, alphas, n_alpha, act, (const int*)list, (long)count, xTraj, uTraj, J, (int*)alpha_idx, (long)batch, T);
     } else {
-        const unsigned blocks = (unsigned)((batch + 3) / 4);
+        const unsigned blocks = (unsigned)((nslot + 3) / 4);
         hipLaunchKernelGGL((zm::rollout_linesearch_kernel<16>), dim3(blocks), dim3(64), 0, st, md, cs, hc, x0, l, L, xPrev,
-                           uPrev, alphas, n_alpha, act, xTraj, uTraj, J, (int*)alpha_idx, (long)batch, T);
+                           uPrev, alphas, n_alpha, act, (const int*)list, (long)count, xTraj, uTraj, J, (int*)alpha_idx, (long)batch, T);
     }
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
+}
+
+extern "C" int zm_rollout_linesearch_f64(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0, const double* l,
+                                         const double* L, const double* xPrev, const double* uPrev, const double* alphas,
+                                         int n_alpha, const int32_t* active, double* xTraj, double* uTraj, double* J,
+                                         int32_t* alpha_idx, int64_t batch, int T, void* stream) {
+    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
+    return rollout_impl(model, cost, x0, l, L, xPrev, uPrev, alphas, n_alpha, active, nullptr, 0, xTraj, uTraj, J, alpha_idx,
+                        batch, T, stream);
+}
+
+extern "C" int zm_rollout_linesearch_list_f64(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0,
+                                              const double* l, const double* L, const double* xPrev, const double* uPrev,
+                                              const double* alphas, int n_alpha, const int32_t* list, int64_t count,
+                                              double* xTraj, double* uTraj, double* J, int32_t* alpha_idx, int64_t batch, int T,
+                                              void* stream) {
+    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
+    if (!list) return zm::set_error(ZM_EINVAL, "zm_rollout_linesearch_list_f64: null list");
+    return rollout_impl(model, cost, x0, l, L, xPrev, uPrev, alphas, n_alpha, nullptr, list, count, xTraj, uTraj, J, alpha_idx,
+                        batch, T, stream);
 }

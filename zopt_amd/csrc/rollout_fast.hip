@@ -30,6 +30,8 @@ struct FastArgs {
     const double* uPrev;
     const double* alphas;
     const int* active;
+    const int* list;   // optional: trajectory ids to process (slot -> id), `count` of them; else slots are ids 0..batch-1
+    long count;
     double* xTraj;
     double* uTraj;
     double* J;
@@ -122,8 +124,10 @@ __device__ __forceinline__ void rollout_ls_body(const FastArgs& g, const double*
                                                 const double* As, const double* Bs, double (*pol)[4][PSZ + 4]) {
     const int lane = threadIdx.x;
     const int grp = lane >> 4, a = lane & 15;
-    const long traj = (long)blockIdx.x * 4 + grp;
-    const bool live = (traj < g.batch) && (g.active == nullptr || g.active[traj < g.batch ? traj : 0] != 0);
+    const long slot = (long)blockIdx.x * 4 + grp;
+    const long nslot = g.list ? g.count : g.batch;
+    const long traj = (slot < nslot) ? (g.list ? (long)g.list[slot] : slot) : 0;
+    const bool live = (slot < nslot) && (g.active == nullptr || g.active[traj] != 0);
     const long t = live ? traj : 0;
     const int T = g.T;
     const double alpha = g.alphas[a];
@@ -291,7 +295,8 @@ __global__ __launch_bounds__(64) void rollout_ls_fast_kernel(const FastArgs g) {
 
 template <int KIND>
 static int launch_fast(const FastArgs& g, hipStream_t st) {
-    hipLaunchKernelGGL((rollout_ls_fast_kernel<KIND>), dim3((unsigned)((g.batch + 3) / 4)), dim3(64), 0, st, g);
+    const long nslot = g.list ? g.count : g.batch;
+    hipLaunchKernelGGL((rollout_ls_fast_kernel<KIND>), dim3((unsigned)((nslot + 3) / 4)), dim3(64), 0, st, g);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }
@@ -299,9 +304,10 @@ static int launch_fast(const FastArgs& g, hipStream_t st) {
 // Fast path dispatch: (n, m) = (12, 4), 16 step sizes.
 int rollout_fast_dispatch(const zm_model_t& md, const double* Q, const double* R, const double* Qf,
                           const double* x0, const double* l, const double* L, const double* xPrev, const double* uPrev,
-                          const double* alphas, const int* active, double* xTraj, double* uTraj, double* J, int* idx,
-                          int64_t batch, int T, hipStream_t st) {
-    FastArgs g{md.A, md.B, md.dt, Q, R, Qf, x0, l, L, xPrev, uPrev, alphas, active, xTraj, uTraj, J, idx, (long)batch, T};
+                          const double* alphas, const int* active, const int* list, int64_t count, double* xTraj,
+                          double* uTraj, double* J, int* idx, int64_t batch, int T, hipStream_t st) {
+    FastArgs g{md.A, md.B, md.dt, Q, R, Qf, x0, l, L, xPrev, uPrev, alphas, active, list, (long)count, xTraj, uTraj, J, idx,
+               (long)batch, T};
     if (md.kind == ZM_MODEL_QUADCOPTER) return launch_fast<ZM_MODEL_QUADCOPTER>(g, st);
     return launch_fast<ZM_MODEL_LINEAR>(g, st);
 }

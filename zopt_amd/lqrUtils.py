@@ -59,16 +59,33 @@ def discreteFiniteHorizonLqr(A, B, Q, R, N):
     native32 = fp32_in and (n > 12 or m > 4)
     dt = torch.float32 if native32 else torch.float64
     dev = [arr.to_device(X, dt) for X in (A, B, Q, R)]
-    # the reference scans xs = arange(N) over the first N steps of each array
-    dA, dB, dQ, dR = [x[..., :N, :, :].contiguous() if x.shape[-3] != N else x for x in dev]
     batch = 1
     for d in lead:
         batch *= int(d)
-    dL = torch.empty(lead + (N, m, n), dtype=dt, device=dA.device)
+    out_dt = torch.float32 if fp32_in else torch.float64
+    if batch == 0:
+        return arr.result_like(torch.empty(lead + (N, m, n), dtype=out_dt, device=dev[0].device), A)
+    # The reference scans xs = arange(N) over the first N steps but starts from V = Q[-1] of the WHOLE array
+    # (lqrUtils.py:172).  The kernel takes the last step's Q as terminal value, so over-long inputs get one extra step
+    # (A = 0, B = 0, Q = Q[-1], R = I): it returns L = 0 and hands V = Q[-1] to step N-1.
+    Tk = N
+    if any(x.shape[-3] != N for x in dev):
+        dA, dB, dQ, dR = dev
+        Tk = N + 1
+        eye = torch.eye(m, dtype=dt, device=dA.device).expand(lead + (1, m, m))
+        dA = torch.cat([dA[..., :N, :, :], torch.zeros_like(dA[..., :1, :, :])], dim=-3).contiguous()
+        dB = torch.cat([dB[..., :N, :, :], torch.zeros_like(dB[..., :1, :, :])], dim=-3).contiguous()
+        dQ = torch.cat([dQ[..., :N, :, :], dQ[..., -1:, :, :]], dim=-3).contiguous()
+        dR = torch.cat([dR[..., :N, :, :], eye], dim=-3).contiguous()
+    else:
+        dA, dB, dQ, dR = dev
+    dL = torch.empty(lead + (Tk, m, n), dtype=dt, device=dA.device)
     fn = _lib.lib().zm_lqr_backward_f32 if native32 else _lib.lib().zm_lqr_backward_f64
-    rc = fn(dA.data_ptr(), dB.data_ptr(), dQ.data_ptr(), dR.data_ptr(), dL.data_ptr(), batch, N, n, m,
+    rc = fn(dA.data_ptr(), dB.data_ptr(), dQ.data_ptr(), dR.data_ptr(), dL.data_ptr(), batch, Tk, n, m,
             ctypes.c_void_p(arr.stream_ptr(dA)))
     _lib.check(rc, "discreteFiniteHorizonLqr")
+    if Tk != N:
+        dL = dL[..., :N, :, :].contiguous()
     if fp32_in and not native32:
         dL = dL.to(torch.float32)
     return arr.result_like(dL, A)
@@ -107,7 +124,7 @@ def discreteInfiniteHorizonLqr(A, B, Q, R, tol=1e-14, maxIter=200000, return_val
     dL = torch.empty(lead + (m, n), dtype=dt, device=dA.device)
     dP = torch.empty(lead + (n, n), dtype=dt, device=dA.device)
     its = torch.empty(lead, dtype=torch.int32, device=dA.device)
-    rc = _lib.lib().zm_dare_f64(dA.data_ptr(), dB.data_ptr(), dQ.data_ptr(), dR.data_ptr(), dL.data_ptr(), dP.data_ptr(),
+    rc = 0 if batch == 0 else _lib.lib().zm_dare_f64(dA.data_ptr(), dB.data_ptr(), dQ.data_ptr(), dR.data_ptr(), dL.data_ptr(), dP.data_ptr(),
                                 its.data_ptr(), batch, n, m, float(tol), int(maxIter), ctypes.c_void_p(arr.stream_ptr(dA)))
     _lib.check(rc, "discreteInfiniteHorizonLqr")
     fp32_in = (arr.is_torch(A) and A.dtype == torch.float32) or (not arr.is_torch(A) and np.asarray(A).dtype == np.float32)
@@ -147,23 +164,39 @@ def bilinearAffineLqr(A, B, d, Q, R, H, q, r, q0, N):
     if N < 1:
         _shape_error("N must be >= 1")
     dt = torch.float64
-    dev = []
-    for name, X, tail in spec:
-        t = arr.to_device(X, dt)
-        if t.shape[len(lead)] != N:
-            t = t.narrow(len(lead), 0, N).contiguous()
-        dev.append(t)
-    dA, dB, dd, dQ, dR, dH, dq, dr = dev
+    dev = [arr.to_device(X, dt) for name, X, tail in spec]
     batch = 1
     for s_ in lead:
         batch *= int(s_)
-    dL = torch.empty(lead + (N, m, n), dtype=dt, device=dA.device)
-    dl = torch.empty(lead + (N, m), dtype=dt, device=dA.device)
+    fp32_in = (arr.is_torch(A) and A.dtype == torch.float32) or (not arr.is_torch(A) and np.asarray(A).dtype == np.float32)
+    if batch == 0:
+        odt = torch.float32 if fp32_in else dt
+        return (arr.result_like(torch.empty(lead + (N, m, n), dtype=odt, device=dev[0].device), A),
+                arr.result_like(torch.empty(lead + (N, m), dtype=odt, device=dev[0].device), A))
+    # Over-long inputs: the reference scans the first N steps from the carry (Q[-1], q[-1], q0[-1]) of the WHOLE arrays
+    # (lqrUtils.py:261).  One extra step (A = B = d = H = r = 0, Q = Q[-1], q = q[-1], R = I) reproduces that carry.
+    ax = len(lead)
+    Tk = N
+    if any(t.shape[ax] != N for t in dev):
+        Tk = N + 1
+        dA, dB, dd, dQ, dR, dH, dq, dr = dev
+        head = lambda t: t.narrow(ax, 0, N)
+        last = lambda t: t.narrow(ax, t.shape[ax] - 1, 1)
+        zero = lambda t: torch.zeros_like(t.narrow(ax, 0, 1))
+        eye = torch.eye(m, dtype=dt, device=dA.device).expand(lead + (1, m, m))
+        dev = [torch.cat([head(dA), zero(dA)], ax), torch.cat([head(dB), zero(dB)], ax), torch.cat([head(dd), zero(dd)], ax),
+               torch.cat([head(dQ), last(dQ)], ax), torch.cat([head(dR), eye], ax), torch.cat([head(dH), zero(dH)], ax),
+               torch.cat([head(dq), last(dq)], ax), torch.cat([head(dr), zero(dr)], ax)]
+        dev = [t.contiguous() for t in dev]
+    dA, dB, dd, dQ, dR, dH, dq, dr = dev
+    dL = torch.empty(lead + (Tk, m, n), dtype=dt, device=dA.device)
+    dl = torch.empty(lead + (Tk, m), dtype=dt, device=dA.device)
     rc = _lib.lib().zm_lqr_backward_affine_f64(dA.data_ptr(), dB.data_ptr(), dd.data_ptr(), dQ.data_ptr(), dR.data_ptr(),
                                                dH.data_ptr(), dq.data_ptr(), dr.data_ptr(), dL.data_ptr(), dl.data_ptr(),
-                                               batch, N, n, m, ctypes.c_void_p(arr.stream_ptr(dA)))
+                                               batch, Tk, n, m, ctypes.c_void_p(arr.stream_ptr(dA)))
     _lib.check(rc, "bilinearAffineLqr")
-    fp32_in = (arr.is_torch(A) and A.dtype == torch.float32) or (not arr.is_torch(A) and np.asarray(A).dtype == np.float32)
+    if Tk != N:
+        dL, dl = dL.narrow(ax, 0, N).contiguous(), dl.narrow(ax, 0, N).contiguous()
     if fp32_in:
         dL, dl = dL.to(torch.float32), dl.to(torch.float32)
     return arr.result_like(dL, A), arr.result_like(dl, A)
