@@ -16,72 +16,93 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+__device__ __forceinline__ double jac_rsqrt(const double x) {   // 1/sqrt(x), x > 0: hardware estimate + 2 Newton steps
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * __builtin_fma(-0.5 * x, y * y, 1.5);
+    y = y * __builtin_fma(-0.5 * x, y * y, 1.5);
+    return y;
+}
+__device__ __forceinline__ double jac_rcp(const double a) {     // 1/a: hardware estimate + 2 Newton steps
+    double r = __builtin_amdgcn_rcp(a);
+    r = __builtin_fma(r, __builtin_fma(-a, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-a, r, 1.0), r);
+    return r;
+}
+
 // In: As (PK*PLD doubles) holds the SYMMETRISED matrix in its leading k x k block.  Scratch: Vs (PK*PLD), cs (PK), pq (PK).
 // Out: As[i*PLD + j] = (V max(w, eps) V^T)[i][j].  Must be called by all 64 lanes of one wave.
+//
+// Work split: 8 lanes per rotation pair (pair = lane >> 3, sub = lane & 7), every lane computes its pair's rotation itself
+// from (a_pp, a_qq, a_pq) -- no exchange of rotation parameters -- and applies it to rows sub and sub+8 of the column pair
+// (A and V), then, after one wave-level sync, to columns sub and sub+8 of the row pair (A).  Two syncs per round, no integer
+// division, reciprocal / reciprocal-square-root by Newton steps.  A rotation is skipped when
+// a_pq^2 <= 2^-104 |a_pp a_qq|; the sweeps stop after the first one that rotated nothing (or after 20).
 __device__ __forceinline__ void psd_project_lds(double* As, double* Vs, double* cs, int* pq, const int k,
                                                 const double eps, const int lane) {
+    (void)pq;
     const int K = (k + 1) & ~1;  // even number of round-robin players; index k (if k is odd) is a bye
-    for (int e = lane; e < k * k; e += 64) Vs[(e / k) * PLD + (e % k)] = ((e / k) == (e % k)) ? 1.0 : 0.0;
+    const int pr = lane >> 3, sub = lane & 7;
+    {   // V <- I on the full padded tile
+        const int i = lane & 15, jb = lane >> 4;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) Vs[i * PLD + jb + 4 * jj] = (i == jb + 4 * jj) ? 1.0 : 0.0;
+    }
     wave_lds_sync();
+    const bool pair_on = pr < (K >> 1);
     for (int sweep = 0; sweep < 20; ++sweep) {
         bool rotated = false;
         for (int r = 0; r < K - 1; ++r) {
-            bool rot = false;
-            if (lane < K / 2) {
-                int p, q;
-                if (lane == 0) {
-                    p = K - 1;
-                    q = r;
-                } else {
-                    p = (r + lane) % (K - 1);
-                    q = (r - lane + (K - 1)) % (K - 1);
-                }
-                if (p > q) {
-                    const int t = p;
-                    p = q;
-                    q = t;
-                }
-                double c = 1.0, s = 0.0;
-                if (q < k) {
-                    const double app = As[p * PLD + p], aqq = As[q * PLD + q], apq = As[p * PLD + q];
-                    if (apq != 0.0 && __builtin_fabs(apq) > 0x1p-52 * __builtin_sqrt(__builtin_fabs(app * aqq))) {
-                        const double tau = (aqq - app) / (2.0 * apq);
-                        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (__builtin_fabs(tau) + __builtin_sqrt(1.0 + tau * tau));
-                        c = 1.0 / __builtin_sqrt(1.0 + t * t);
-                        s = t * c;
-                        rot = true;
-                    }
-                } else {
-                    q = p;  // bye: identity on a single index
-                }
-                pq[2 * lane] = p;
-                pq[2 * lane + 1] = q;
-                cs[2 * lane] = c;
-                cs[2 * lane + 1] = s;
+            // round-robin pairing of K players: player K-1 stays, the others rotate (no modulo: one conditional subtract)
+            int p, q;
+            if (pr == 0) {
+                p = K - 1;
+                q = r;
+            } else {
+                p = r + pr;
+                p = p >= K - 1 ? p - (K - 1) : p;
+                q = r - pr + (K - 1);
+                q = q >= K - 1 ? q - (K - 1) : q;
+            }
+            if (p > q) {
+                const int t = p;
+                p = q;
+                q = t;
+            }
+            const bool on = pair_on && q < k;   // q == k: bye
+            p = on ? p : 0;
+            q = on ? q : 0;
+            const double app = As[p * PLD + p], aqq = As[q * PLD + q], apq = As[p * PLD + q];
+            const bool rot = on && (apq * apq > 0x1p-104 * __builtin_fabs(app * aqq));
+            double c = 1.0, s = 0.0;
+            if (rot) {
+                // t = sgn(d) 2 a_pq / (|d| + sqrt(d^2 + 4 a_pq^2)),  d = a_qq - a_pp   (the smaller root of t^2 + 2 tau t - 1)
+                const double d = aqq - app, b2 = 2.0 * apq;
+                const double x = __builtin_fma(d, d, b2 * b2);
+                const double h = x * jac_rsqrt(x);
+                const double t = (d >= 0.0 ? b2 : -b2) * jac_rcp(__builtin_fabs(d) + h);
+                c = jac_rsqrt(__builtin_fma(t, t, 1.0));
+                s = t * c;
             }
             rotated |= (__ballot(rot) != 0ull);
-            wave_lds_sync();
-            // columns p,q of A and V:  X[:, p] <- c X[:,p] - s X[:,q],  X[:, q] <- s X[:,p] + c X[:,q]
-            for (int e = lane; e < (K / 2) * k; e += 64) {
-                const int pr = e / k, i = e % k;
-                const int p = pq[2 * pr], q = pq[2 * pr + 1];
-                const double c = cs[2 * pr], s = cs[2 * pr + 1];
-                if (p != q) {
+            // columns p, q of A and V, rows sub and sub+8:  X[:,p] <- c X[:,p] - s X[:,q],  X[:,q] <- s X[:,p] + c X[:,q]
+            if (rot) {
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int i = sub + 8 * h2;
                     const double ap = As[i * PLD + p], aq = As[i * PLD + q];
+                    const double vp = Vs[i * PLD + p], vq = Vs[i * PLD + q];
                     As[i * PLD + p] = c * ap - s * aq;
                     As[i * PLD + q] = s * ap + c * aq;
-                    const double vp = Vs[i * PLD + p], vq = Vs[i * PLD + q];
                     Vs[i * PLD + p] = c * vp - s * vq;
                     Vs[i * PLD + q] = s * vp + c * vq;
                 }
             }
             wave_lds_sync();
-            // rows p,q of A
-            for (int e = lane; e < (K / 2) * k; e += 64) {
-                const int pr = e / k, j = e % k;
-                const int p = pq[2 * pr], q = pq[2 * pr + 1];
-                const double c = cs[2 * pr], s = cs[2 * pr + 1];
-                if (p != q) {
+            // rows p, q of A, columns sub and sub+8
+            if (rot) {
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int j = sub + 8 * h2;
                     const double ap = As[p * PLD + j], aq = As[q * PLD + j];
                     As[p * PLD + j] = c * ap - s * aq;
                     As[q * PLD + j] = s * ap + c * aq;
@@ -92,13 +113,22 @@ __device__ __forceinline__ void psd_project_lds(double* As, double* Vs, double* 
         if (!rotated) break;
     }
     // A <- V max(w, eps) V^T   (the clamped eigenvalues are copied out of the diagonal first)
-    if (lane < k) cs[lane] = As[lane * PLD + lane] > eps ? As[lane * PLD + lane] : eps;
+    if (lane < PK) cs[lane] = (lane < k) ? (As[lane * PLD + lane] > eps ? As[lane * PLD + lane] : eps) : 0.0;
     wave_lds_sync();
-    for (int e = lane; e < k * k; e += 64) {
-        const int i = e / k, j = e % k;
-        double acc = 0.0;
-        for (int t = 0; t < k; ++t) acc = __builtin_fma(Vs[i * PLD + t] * cs[t], Vs[j * PLD + t], acc);
-        As[i * PLD + j] = acc;
+    {
+        const int i = lane & 15, jb = lane >> 4;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int t = 0; t < k; ++t) {
+            const double vi = Vs[i * PLD + t] * cs[t];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[jj] = __builtin_fma(vi, Vs[(jb + 4 * jj) * PLD + t], acc[jj]);
+        }
+        wave_lds_sync();
+        if (i < k) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                if (jb + 4 * jj < k) As[i * PLD + jb + 4 * jj] = acc[jj];
+        }
     }
     wave_lds_sync();
 }

@@ -215,8 +215,8 @@ extern "C" int zm_quadratize_cost_f64(const zm_quadcost_t* cost, int n, int m, c
                                       const int32_t* active, double* c, double* c_x, double* c_u, double* v, double* v_x,
                                       double* c_xx, double* c_ux, double* c_uu, double* v_xx, int64_t batch, int T,
                                       void* stream) {
-    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
-    if (!cost || !cost->Q || !cost->R || !cost->Qf || !xTraj || !uTraj)
+    /* batch == 0 is a valid call: it still writes the trajectory-independent Hessians (xTraj, uTraj may then be NULL) */
+    if (!cost || !cost->Q || !cost->R || !cost->Qf || (batch != 0 && (!xTraj || !uTraj)))
         return zm::set_error(ZM_EINVAL, "zm_quadratize_cost_f64: null pointer");
     if (n < 1 || n > zm::MAXN || m < 1 || m > zm::MAXM)
         return zm::set_error(ZM_EUNSUPPORTED, "zm_quadratize_cost_f64: (n=%d, m=%d) not covered", n, m);
