@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8192)
     ap.add_argument("--T", type=int, default=100)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--ddp", action="store_true", help="differentialDynamicProgramming (R = 0.2 I as in its demo) instead of iterativeLqr")
     args = ap.parse_args()
     import torch
     from zopt_amd import ilqrUtils, models
@@ -25,19 +26,20 @@ def main():
     x0 = np.zeros((args.batch, 12))
     x0[:, 9:12] = rng.uniform(-10, 10, (args.batch, 3))
     ug = np.tile(models.QuadcopterEuler.uTrim, (args.batch, args.T, 1))
-    cost = models.QuadraticCost(np.eye(12), np.eye(4), 10 * np.eye(12))
+    cost = models.QuadraticCost(np.eye(12), (0.2 if args.ddp else 1.0) * np.eye(4), 10 * np.eye(12))
+    solve = ilqrUtils.differentialDynamicProgramming if args.ddp else ilqrUtils.iterativeLqr
     model = models.QuadcopterEuler(0.1)
     tx0, tug = torch.as_tensor(x0, device="cuda"), torch.as_tensor(ug, device="cuda")
-    ilqrUtils.iterativeLqr(model, cost, cost, tx0[:64], tug[:64])       # warm-up
+    solve(model, cost, cost, tx0[:64], tug[:64])       # warm-up
     torch.cuda.synchronize()
     times = []
     for _ in range(args.reps):
         t0 = time.perf_counter()
-        traj, L, J, conv = ilqrUtils.iterativeLqr(model, cost, cost, tx0, tug)
+        traj, L, J, conv = solve(model, cost, cost, tx0, tug)
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
     t = min(times)
-    print(json.dumps({"workload": f"iterativeLqr quadcopter n=12 m=4 T={args.T} batch={args.batch} fp64",
+    print(json.dumps({"workload": f"{'differentialDynamicProgramming' if args.ddp else 'iterativeLqr'} quadcopter n=12 m=4 T={args.T} batch={args.batch} fp64",
                       "solve_ms": t * 1e3, "converged_frac": float(conv.double().mean().item()),
                       "J_mean": float(J.mean().item()),
                       "trajectories_per_s": args.batch / t}))

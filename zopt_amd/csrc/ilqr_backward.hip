@@ -65,6 +65,7 @@ struct IlqrAddr {
     double* pOut;        // L_k[g][c] (c < n) or l_k[g] (c == NP)
     int dF, dC, sF, sC, sCu, scv, sOut, sd;
     bool rowok[KS], vF[KS], vC[KS], vCu, vcv, vOut, vL, cA;
+    bool warm_v = false;   // MODE 2: the Jacobi eigenvector buffer holds the previous step's result
     double cu_pad;
 };
 
@@ -149,7 +150,8 @@ __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], 
             if (e < k * k) jA[(e / k) * PLD + (e % k)] = sy[r];
         }
         ilqr_lds_sync();
-        psd_project_lds(jA, jV, jcs, jpq, k, 1e-3, lane);
+        psd_project_lds(jA, jV, jcs, jpq, k, 1e-3, lane, a.warm_v);
+        a.warm_v = true;   // jV now holds eigenvectors of a neighbouring step's matrix
 #pragma unroll
         for (int r = 0; r < 4; ++r) pz[r] = (a.zc[r] >= 0) ? jA[a.zc[r]] : 0.0;
     }

@@ -37,15 +37,43 @@ __device__ __forceinline__ double jac_rcp(const double a) {     // 1/a: hardware
 // (A and V), then, after one wave-level sync, to columns sub and sub+8 of the row pair (A).  Two syncs per round, no integer
 // division, reciprocal / reciprocal-square-root by Newton steps.  A rotation is skipped when
 // a_pq^2 <= 2^-104 |a_pp a_qq|; the sweeps stop after the first one that rotated nothing (or after 20).
+//
+// warm = true: Vs already holds an orthogonal matrix V0 (the eigenvectors this routine left behind for a NEARBY matrix, e.g.
+// the previous step of a DDP sweep).  The iteration then starts from V0^T A V0 -- nearly diagonal -- and accumulates onto V0:
+// same result, typically 2-3 sweeps instead of 6-8.
 __device__ __forceinline__ void psd_project_lds(double* As, double* Vs, double* cs, int* pq, const int k,
-                                                const double eps, const int lane) {
+                                                const double eps, const int lane, const bool warm = false) {
     (void)pq;
     const int K = (k + 1) & ~1;  // even number of round-robin players; index k (if k is odd) is a bye
     const int pr = lane >> 3, sub = lane & 7;
-    {   // V <- I on the full padded tile
+    if (!warm) {   // V <- I on the full padded tile
         const int i = lane & 15, jb = lane >> 4;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) Vs[i * PLD + jb + 4 * jj] = (i == jb + 4 * jj) ? 1.0 : 0.0;
+    } else {       // A <- V0^T A V0  (two k^3 products through registers; lane owns row i, columns jb + 4 jj)
+        const int i = lane & 15, jb = lane >> 4;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int t = 0; t < k; ++t) {      // T = A V0
+            const double ait = (i < k) ? As[i * PLD + t] : 0.0;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[jj] = __builtin_fma(ait, Vs[t * PLD + jb + 4 * jj], acc[jj]);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) As[i * PLD + jb + 4 * jj] = acc[jj];
+        wave_lds_sync();
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[jj] = 0.0;
+        for (int t = 0; t < k; ++t) {      // V0^T T
+            const double vti = (i < k) ? Vs[t * PLD + i] : 0.0;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[jj] = __builtin_fma(vti, As[t * PLD + jb + 4 * jj], acc[jj]);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) As[i * PLD + jb + 4 * jj] = acc[jj];
+        // the products leave rounding-level asymmetry; the rotations read a_pq from the upper triangle only, both
+        // triangles are transformed identically afterwards
     }
     wave_lds_sync();
     const bool pair_on = pr < (K >> 1);
