@@ -123,10 +123,23 @@ __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], 
     if constexpr (MODE == 2) {
         const int lane = g * 16 + c;
         double z[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int i = 0; i < n; ++i) {
-            const double vxi = sm[80 + i];
+        // the loads of 4 slices (16 per lane) are in flight before their FMAs (unrolled, unconditional: slices i >= n
+        // re-read slice 0 with weight 0); more in flight would cost the second wave per SIMD its registers
 #pragma unroll
-            for (int r = 0; r < 4; ++r) z[r] = __builtin_fma(vxi, a.pz[r][(long)i * a.sz[r]], z[r]);
+        for (int i0 = 0; i0 < NP; i0 += 4) {
+            double fz[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ic = (i0 + i) < n ? (i0 + i) : 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fz[i][r] = a.pz[r][(long)ic * a.sz[r]];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double vxi = (i0 + i) < n ? sm[80 + i0 + i] : 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[r] = __builtin_fma(vxi, fz[i][r], z[r]);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -257,7 +270,7 @@ __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], 
 }
 
 template <int KS, int MODE>
-__global__ __launch_bounds__(64) void ilqr_backward_t16_f64(
+__global__ __launch_bounds__(64, 2) void ilqr_backward_t16_f64(
     const double* __restrict__ f_x, const double* __restrict__ f_u, const double* __restrict__ c_x,
     const double* __restrict__ c_u, const double* __restrict__ c_xx, const double* __restrict__ c_ux,
     const double* __restrict__ c_uu, const double* __restrict__ vf_x, const double* __restrict__ vf_xx,
