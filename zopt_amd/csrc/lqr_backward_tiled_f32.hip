@@ -210,6 +210,8 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled_f32(const float* __rest
                 x[r] = __builtin_fmaf(-ms, x[kk], x[r]);
                 u[r] = __builtin_fmaf(-ms, u[kk], u[r]);
                 ya();
+                if (((kk * 15 - kk * (kk - 1) / 2 + (r - kk - 1)) & 1) != 0) ya();   // an elimination unit is ~1.5 MFMAs long,
+                                                                                     // a substitution unit ~0.5
             }
         }
         bad |= __ballot(!(__builtin_fabsf(pinv[15]) < 3.0e38f));
@@ -219,12 +221,15 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled_f32(const float* __rest
 #pragma unroll
             for (int r = kk + 1; r < 16; ++r) {
                 acc = __builtin_fmaf(-readlane_f(u[kk], r), x[r], acc);
-                ya();
+                if (((kk * 15 - kk * (kk - 1) / 2 + (r - kk - 1)) & 1) == 0) ya();
             }
             x[kk] = acc * pinv[kk];
         }
+        static_assert(4 * NT * NT * NT <= 256, "the 256 ya() calls above must cover the Y_A sequence");
+        // The pivoted path below overwrites x, so the optimiser would sink the whole substitution past the branch -- away from
+        // the MFMAs it is meant to hide under.  Pin the values here.
 #pragma unroll
-        for (int t = 256; t < 4 * NT * NT * NT; ++t) ya();   // (none for NT <= 4)
+        for (int u_ = 0; u_ < 16; ++u_) asm volatile("" : "+v"(x[u_]));
         if (bad != 0ull) {   // wave-uniform, rare: LU with partial pivoting on the copy still in LDS (getrf / getrs order)
 #define S_(r_, j_) Sc[(j_) * TLD + (r_)]
 #pragma unroll 1
