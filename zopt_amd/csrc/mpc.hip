@@ -25,8 +25,9 @@
 // computed by an adjoint sweep) and  v^T w(u=0) - support_box(v) > eps_pinf |v|_inf,  i.e. v separates the dynamics
 // subspace from the box.  The certificate is sound but can need thousands of iterations; an infeasible instance that
 // is not certified within max_iter reports "user_limit".
-#include "zm_common.h"
+#include "mpc_common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace zm {
@@ -118,17 +119,6 @@ __global__ __launch_bounds__(256) void mpc_setup_kernel(const double* __restrict
 // ----------------------------------------------------------------------------------------------------------------
 // solve: one lane per instance
 // ----------------------------------------------------------------------------------------------------------------
-struct MpcArgs {
-    const double* x0;
-    double rho, eps_abs, eps_rel, eps_pinf;
-    int max_iter;
-    int warm;   // 1: the workspace holds the iterates (y, lam) of a previous solve of the same problem family; 2: same, shifted by one step
-    double *ws, *xTraj, *uTraj;
-    int *status, *iters;
-    double* resid;
-    long batch;
-    int N;
-};
 
 // The shared tables are separate `const __restrict__` kernel arguments so that hipcc can prove them read-only and
 // fetch them with scalar loads (wave-uniform addresses) instead of per-lane vector loads held in hundreds of VGPRs.
@@ -437,9 +427,6 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const double* __restrict_
     }
 }
 
-struct MpcTabs {
-    const double *A, *B, *K, *Minv, *x_lb, *x_ub, *u_lb, *u_ub;
-};
 
 template <int NS, int MC>
 static int launch_mpc(const MpcTabs& t, const MpcArgs& g, hipStream_t st) {
@@ -487,6 +474,16 @@ extern "C" int zm_mpc_solve_warm_f64(const double* A, const double* B, const dou
     zm::MpcArgs g{x0, rho, eps_abs, eps_rel, eps_prim_inf, max_iter, warm_start == 2 ? 2 : (warm_start ? 1 : 0), workspace, xTraj, uTraj, (int*)status, (int*)iters, resid,
                   (long)batch, N};
     hipStream_t st = (hipStream_t)stream;
+    // default: 16 lanes per instance with the iterates in LDS (mpc_wave.hip); ZOPT_AMD_MPC_PATH=lane forces the
+    // lane-per-instance kernel below, which also takes the horizons that do not fit LDS
+    static const bool force_lane = [] {
+        const char* e = getenv("ZOPT_AMD_MPC_PATH");
+        return e && e[0] == 'l';
+    }();
+    if (!force_lane) {
+        const int rc = zm::mpc_wave_dispatch(t, g, n, m, st);
+        if (rc != ZM_EUNSUPPORTED) return rc;
+    }
     if (n == 12 && m == 4) return zm::launch_mpc<12, 4>(t, g, st);
     if (n == 8 && m == 4) return zm::launch_mpc<8, 4>(t, g, st);
     if (n == 4 && m == 2) return zm::launch_mpc<4, 2>(t, g, st);

@@ -1,0 +1,26 @@
+// Shared argument blocks of the MPC solve kernels (mpc.hip: one lane per instance; mpc_wave.hip: 16 lanes per instance).
+#pragma once
+#include "zm_common.h"
+
+namespace zm {
+
+struct MpcArgs {
+    const double* x0;
+    double rho, eps_abs, eps_rel, eps_pinf;
+    int max_iter;
+    int warm;   // 1: the workspace holds the iterates (y, lam) of a previous solve of the same problem family; 2: same, shifted by one step
+    double *ws, *xTraj, *uTraj;
+    int *status, *iters;
+    double* resid;
+    long batch;
+    int N;
+};
+
+struct MpcTabs {
+    const double *A, *B, *K, *Minv, *x_lb, *x_ub, *u_lb, *u_ub;
+};
+
+// mpc_wave.hip: 16 lanes per instance, iterates in LDS.  ZM_EUNSUPPORTED if the shape / horizon does not fit.
+int mpc_wave_dispatch(const MpcTabs& t, const MpcArgs& g, int n, int m, hipStream_t st);
+
+}  // namespace zm

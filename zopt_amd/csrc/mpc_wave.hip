@@ -1,0 +1,340 @@
+// K9-W  mpc_solve_wave -- the ADMM of mpc.hip with 16 LANES PER INSTANCE (4 instances per wave64), iterates in LDS.
+//
+// Same algorithm, same termination and certificate as mpc_solve_kernel (mpc.hip; problem: zopt/mpcUtils.py:48-59): only
+// the mapping differs.  One lane per instance leaves an MI355X nearly idle at the batch sizes MPC is used with (1024
+// instances = 16 waves) and makes every ADMM iteration a chain of 60 x ~500 dependent FMAs in one lane.  Here lane i of a
+// 16-lane group holds component i of the state-sized vectors (lanes 0..m-1 also the control-sized ones) and ROW / COLUMN i
+// of A, B, K_k, Suu_k^-1; a mat-vec is NL broadcasts (DPP row_newbcast, no LDS) + NL FMAs per lane:
+//     backward stage:  p = p' - rho z_x;  [Qu | A^T p] in one pass over p;  [kf | K^T Qu] in one pass over Qu
+//     forward  stage:  [K x | A x] in one pass over x;  + B u;  clip / dual update on the lane's own components
+// ~160 instructions per stage instead of ~1000.  The iterates y, lam, kf (and the certificate's r) live in LDS, one private
+// slot per lane and stage: no cross-lane LDS traffic, hence no barrier anywhere in the loop; HBM is touched only for the
+// tables K_k, Suu_k^-1 (L2-resident, fetched one stage ahead) and at entry / exit (warm start, results).
+#include "mpc_common.h"
+
+#include <hip/hip_runtime.h>
+
+namespace zm {
+
+template <int L>
+__device__ __forceinline__ double bc16(const double v) {   // value of lane L of this lane's 16-lane row
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + L, 0xf, 0xf, false);   // row_newbcast:L
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + L, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// a1 += sum_l c1[l] v_l,  a2 += sum_l c2[l] v_l   over the first NL lanes of the row (one broadcast feeds both)
+template <int NL, int L = 0>
+__device__ __forceinline__ void mv2(const double (&c1)[NL], const double (&c2)[NL], const double v, double& a1, double& a2) {
+    if constexpr (L < NL) {
+        const double b = bc16<L>(v);
+        a1 = __builtin_fma(c1[L], b, a1);
+        a2 = __builtin_fma(c2[L], b, a2);
+        mv2<NL, L + 1>(c1, c2, v, a1, a2);
+    }
+}
+template <int NL, int L = 0>
+__device__ __forceinline__ void mv1(const double (&c1)[NL], const double v, double& a1) {
+    if constexpr (L < NL) {
+        a1 = __builtin_fma(c1[L], bc16<L>(v), a1);
+        mv1<NL, L + 1>(c1, v, a1);
+    }
+}
+__device__ __forceinline__ double row_max(double v) {
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) v = __builtin_fmax(v, __shfl_xor(v, off, 16));
+    return v;
+}
+__device__ __forceinline__ double row_sum(double v) {
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, 16);
+    return v;
+}
+
+// LDS per group and stage (doubles): yx[16] lx[16] rx[16] | yu[4] lu[4] ru[4] kf[4]
+constexpr int WS_STAGE = 64;
+
+template <int NS, int MC>
+__global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                            const double* __restrict__ Ktab, const double* __restrict__ Mtab,
+                                                            const double* __restrict__ x_lb, const double* __restrict__ x_ub,
+                                                            const double* __restrict__ u_lb, const double* __restrict__ u_ub,
+                                                            const MpcArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int W = NS + MC;
+    const int lane = threadIdx.x, grp = lane >> 4, li = lane & 15;
+    const long inst_raw = (long)blockIdx.x * 4 + grp;
+    const bool live = inst_raw < g.batch;          // uniform over the 16-lane group
+    const long inst = live ? inst_raw : g.batch - 1;   // idle groups shadow the last instance and never store
+    const int N = g.N;
+    const double rho = g.rho;
+    const bool sx = li < NS, su = li < MC;         // this lane owns a state / a control component
+    const int ix = sx ? li : 0, iu = su ? li : 0;
+    double* base = lds + (long)grp * N * WS_STAGE;
+    double* yx = base + li;                        // + k * WS_STAGE
+    double* lx = base + 16 + li;
+    double* rx = base + 32 + li;
+    double* yu = base + 48 + iu;
+    double* lu = base + 52 + iu;
+    double* ru = base + 56 + iu;
+    double* kf = base + 60 + iu;
+
+    // rows / columns of the shared matrices (zero outside the lane's role)
+    double Arow[NS], Acol[NS], Bcol[NS], Brow[MC];
+#pragma unroll
+    for (int l = 0; l < NS; ++l) {
+        const double ar = A[ix * NS + l], ac = A[l * NS + ix], bcv = B[l * MC + iu];
+        Arow[l] = sx ? ar : 0.0;
+        Acol[l] = sx ? ac : 0.0;
+        Bcol[l] = su ? bcv : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+        const double br = B[ix * MC + j];
+        Brow[j] = sx ? br : 0.0;
+    }
+    const double xlo = sx ? x_lb[ix] : -__builtin_inf(), xhi = sx ? x_ub[ix] : __builtin_inf();
+    const double ulo = su ? u_lb[iu] : -__builtin_inf(), uhi = su ? u_ub[iu] : __builtin_inf();
+    const double x0 = sx ? g.x0[inst * NS + ix] : 0.0;
+    // x_0 = x0 is box-constrained too (mpcUtils.py:56,58): group-wide AND over the state lanes
+    const double viol = (sx && !(x0 >= xlo && x0 <= xhi)) ? 1.0 : 0.0;
+    const bool x0_in = row_max(viol) == 0.0;
+
+    // per-instance block of the caller's workspace: [y (N,W) | lam (N,W) | kf (N,MC), ok flag, spare | unused]
+    double* wsi = g.ws + inst * (4L * N * W);
+    double* okflag = wsi + 2L * N * W + (long)N * MC;
+    const bool warm = g.warm && (*okflag == 1.0);
+    for (int k = 0; k < N; ++k) {
+        const int ks = (g.warm == 2 && k + 1 < N) ? k + 1 : k;    // shifted warm start: iterate k <- iterate k+1
+        const double wyx = warm ? wsi[(long)ks * W + ix] : 0.0, wlx = warm ? wsi[(long)N * W + (long)ks * W + ix] : 0.0;
+        const double wyu = warm ? wsi[(long)ks * W + NS + iu] : 0.0, wlu = warm ? wsi[(long)N * W + (long)ks * W + NS + iu] : 0.0;
+        yx[k * WS_STAGE] = sx ? wyx : 0.0;
+        lx[k * WS_STAGE] = sx ? wlx : 0.0;
+        rx[k * WS_STAGE] = 0.0;
+        if (su) {
+            yu[k * WS_STAGE] = wyu;
+            lu[k * WS_STAGE] = wlu;
+            ru[k * WS_STAGE] = 0.0;
+            kf[k * WS_STAGE] = 0.0;
+        }
+    }
+
+    // table rows / columns of one stage: K row (control lanes), K column (state lanes), Suu^-1 row (control lanes)
+    auto load_tab = [&](const int k, double (&Krow)[NS], double (&Kcol)[MC], double (&Mrow)[MC]) {
+        const double* Kk = Ktab + (long)k * MC * NS;
+        const double* Mk = Mtab + (long)k * MC * MC;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const double v = Kk[iu * NS + i];
+            Krow[i] = su ? v : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < MC; ++j) {
+            const double v = Kk[j * NS + ix], w = Mk[iu * MC + j];
+            Kcol[j] = sx ? v : 0.0;
+            Mrow[j] = su ? w : 0.0;
+        }
+    };
+
+    int status = x0_in ? 0 : ZM_MPC_INFEASIBLE;
+    int it = 0;
+    double rp = 0.0, rd = 0.0;
+    bool done = !live || status != 0;              // group-uniform
+    for (int gi = 0; gi < g.max_iter; ++gi) {
+        if (__all(done)) break;
+        const bool chk = ((gi + 1) % 25) == 0;
+        // ---- backward affine sweep
+        double pp = 0.0;   // (A^T p - K^T Qu) of the stage above
+        {
+            double Krow[NS], Kcol[MC], Mrow[MC];
+            load_tab(N - 1, Krow, Kcol, Mrow);
+#pragma unroll 1
+            for (int k = N - 1; k >= 0; --k) {
+                double Krn[NS], Kcn[MC], Mrn[MC];
+                load_tab(k > 0 ? k - 1 : 0, Krn, Kcn, Mrn);   // one stage ahead
+                const double zx = -rho * (yx[k * WS_STAGE] - lx[k * WS_STAGE]);
+                const double zu = su ? -rho * (yu[k * WS_STAGE] - lu[k * WS_STAGE]) : 0.0;
+                const double kfo = kf[k * WS_STAGE];
+                const double p = pp + zx;             // costate of x_{k+1}
+                double qu = zu, pa = 0.0;
+                mv2<NS>(Bcol, Acol, p, qu, pa);       // Qu = -rho z_u + B^T p (control lanes);  A^T p (state lanes)
+                double kfv = 0.0, pk = 0.0;
+                mv2<MC>(Mrow, Kcol, qu, kfv, pk);     // kf = Suu^-1 Qu;  K^T Qu
+                if (su) kf[k * WS_STAGE] = done ? kfo : kfv;
+                pp = pa - pk;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) Krow[i] = Krn[i];
+#pragma unroll
+                for (int j = 0; j < MC; ++j) {
+                    Kcol[j] = Kcn[j];
+                    Mrow[j] = Mrn[j];
+                }
+                (void)Krow;
+            }
+        }
+        // ---- forward rollout, projection, dual update, residuals
+        double x = x0;
+        double nrp = 0.0, nrd = 0.0, nw = 0.0, ny = 0.0, nl = 0.0, sup = 0.0;
+        {
+            double Krow[NS], Kcol[MC], Mrow[MC];
+            load_tab(0, Krow, Kcol, Mrow);
+#pragma unroll 1
+            for (int k = 0; k < N; ++k) {
+                double Krn[NS], Kcn[MC], Mrn[MC];
+                load_tab(k + 1 < N ? k + 1 : N - 1, Krn, Kcn, Mrn);
+                double ku = 0.0, xn = 0.0;
+                mv2<NS>(Krow, Arow, x, ku, xn);       // K x (control lanes), A x (state lanes)
+                const double u = su ? -kf[k * WS_STAGE] - ku : 0.0;
+                mv1<MC>(Brow, u, xn);                 // + B u
+                {   // state component
+                    const double lold = lx[k * WS_STAGE], yold = yx[k * WS_STAGE];
+                    double yn = xn + lold;
+                    yn = yn < xlo ? xlo : (yn > xhi ? xhi : yn);
+                    const double r = xn - yn, ln = lold + r;
+                    yx[k * WS_STAGE] = (done || !sx) ? yold : yn;
+                    lx[k * WS_STAGE] = (done || !sx) ? lold : ln;
+                    if (chk) rx[k * WS_STAGE] = sx ? r : 0.0;
+                    if (sx) {
+                        if (chk) sup += (r > 0.0) ? r * xhi : ((r < 0.0) ? r * xlo : 0.0);
+                        nrp = __builtin_fmax(nrp, __builtin_fabs(r));
+                        nrd = __builtin_fmax(nrd, __builtin_fabs(yn - yold));
+                        nw = __builtin_fmax(nw, __builtin_fabs(xn));
+                        ny = __builtin_fmax(ny, __builtin_fabs(yn));
+                        nl = __builtin_fmax(nl, __builtin_fabs(ln));
+                    }
+                }
+                if (su) {   // control component
+                    const double lold = lu[k * WS_STAGE], yold = yu[k * WS_STAGE];
+                    double yn = u + lold;
+                    yn = yn < ulo ? ulo : (yn > uhi ? uhi : yn);
+                    const double r = u - yn, ln = lold + r;
+                    yu[k * WS_STAGE] = done ? yold : yn;
+                    lu[k * WS_STAGE] = done ? lold : ln;
+                    if (chk) {
+                        ru[k * WS_STAGE] = r;
+                        sup += (r > 0.0) ? r * uhi : ((r < 0.0) ? r * ulo : 0.0);
+                    }
+                    nrp = __builtin_fmax(nrp, __builtin_fabs(r));
+                    nrd = __builtin_fmax(nrd, __builtin_fabs(yn - yold));
+                    nw = __builtin_fmax(nw, __builtin_fabs(u));
+                    ny = __builtin_fmax(ny, __builtin_fabs(yn));
+                    nl = __builtin_fmax(nl, __builtin_fabs(ln));
+                }
+                x = sx ? xn : 0.0;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) Krow[i] = Krn[i];
+#pragma unroll
+                for (int j = 0; j < MC; ++j) {
+                    Kcol[j] = Kcn[j];
+                    Mrow[j] = Mrn[j];
+                }
+                (void)Kcol;
+                (void)Mrow;
+            }
+        }
+        nrp = row_max(nrp);
+        nrd = row_max(nrd);
+        nw = row_max(nw);
+        ny = row_max(ny);
+        nl = row_max(nl);
+        bool need_cert = false;
+        if (!done) {
+            ++it;
+            rp = nrp;
+            rd = rho * nrd;
+            const double ep = g.eps_abs + g.eps_rel * __builtin_fmax(nw, ny);
+            const double ed = g.eps_abs + g.eps_rel * rho * nl;
+            if (rp <= ep && rd <= ed) {
+                status = ZM_MPC_OPTIMAL;
+                done = true;
+            } else if (!(rp == rp)) {
+                done = true;   // NaN iterates (non-finite data): stop with the limit status
+            } else {
+                need_cert = chk;
+            }
+        }
+        // ---- primal infeasibility certificate (mpc.hip header): adjoint sweep over r = w - y
+        if (chk && __any(need_cert)) {
+            sup = row_sum(sup);
+            double sv = rx[(N - 1) * WS_STAGE];
+            double gmax = 0.0;
+#pragma unroll 1
+            for (int k = N - 1; k >= 0; --k) {
+                double gv = su ? ru[k * WS_STAGE] : 0.0;
+                double sn = (k >= 1) ? rx[(k - 1) * WS_STAGE] : 0.0;
+                mv2<NS>(Bcol, Acol, sv, gv, sn);      // (G^T r)_k = r_u,k + B^T s;   s <- r_x,k-1 + A^T s
+                if (su) gmax = __builtin_fmax(gmax, __builtin_fabs(gv));
+                sv = sx ? sn : 0.0;
+            }
+            gmax = row_max(gmax);
+            const double vw0 = row_sum(sv * x0);
+            if (need_cert && gmax <= g.eps_pinf * rp && (vw0 - sup) > g.eps_pinf * rp) {
+                status = ZM_MPC_INFEASIBLE;
+                done = true;
+            }
+        }
+    }
+    // ---- final trajectory (the dynamics-exact rollout of the last iterate) and the iterates for a later warm start
+    if (live) {
+        double x = x0;
+        if (sx) g.xTraj[(inst * (N + 1)) * NS + ix] = x;
+        double Krow[NS], Kcol[MC], Mrow[MC];
+#pragma unroll 1
+        for (int k = 0; k < N; ++k) {
+            load_tab(k, Krow, Kcol, Mrow);
+            double ku = 0.0, xn = 0.0;
+            mv2<NS>(Krow, Arow, x, ku, xn);
+            const double u = su ? -kf[k * WS_STAGE] - ku : 0.0;
+            mv1<MC>(Brow, u, xn);
+            if (su) g.uTraj[(inst * N + k) * MC + iu] = u;
+            x = sx ? xn : 0.0;
+            if (sx) g.xTraj[(inst * (N + 1) + k + 1) * NS + ix] = x;
+            if (sx) {
+                wsi[(long)k * W + ix] = yx[k * WS_STAGE];
+                wsi[(long)N * W + (long)k * W + ix] = lx[k * WS_STAGE];
+            }
+            if (su) {
+                wsi[(long)k * W + NS + iu] = yu[k * WS_STAGE];
+                wsi[(long)N * W + (long)k * W + NS + iu] = lu[k * WS_STAGE];
+            }
+        }
+        if (li == 0) {
+            g.status[inst] = status ? status : ZM_MPC_USER_LIMIT;
+            *okflag = (status == ZM_MPC_OPTIMAL) ? 1.0 : 0.0;
+            if (g.iters) g.iters[inst] = it;
+            if (g.resid) {
+                g.resid[inst * 2] = rp;
+                g.resid[inst * 2 + 1] = rd;
+            }
+        }
+    }
+}
+
+template <int NS, int MC>
+static int launch_wave(const MpcTabs& t, const MpcArgs& g, hipStream_t st) {
+    const size_t bytes = (size_t)4 * g.N * WS_STAGE * sizeof(double);
+    if (bytes > 150 * 1024) return ZM_EUNSUPPORTED;   // horizon too long for LDS: the lane-per-instance kernel takes it
+    static bool attr_set = false;
+    if (!attr_set) {
+        ZM_HIP_CHECK(hipFuncSetAttribute((const void*)mpc_solve_wave_kernel<NS, MC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         150 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((mpc_solve_wave_kernel<NS, MC>), dim3((unsigned)((g.batch + 3) / 4)), dim3(64), bytes, st, t.A, t.B, t.K,
+                       t.Minv, t.x_lb, t.x_ub, t.u_lb, t.u_ub, g);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+
+int mpc_wave_dispatch(const MpcTabs& t, const MpcArgs& g, int n, int m, hipStream_t st) {
+    if (n == 12 && m == 4) return launch_wave<12, 4>(t, g, st);
+    if (n == 8 && m == 4) return launch_wave<8, 4>(t, g, st);
+    if (n == 4 && m == 2) return launch_wave<4, 2>(t, g, st);
+    if (n == 4 && m == 1) return launch_wave<4, 1>(t, g, st);
+    if (n == 2 && m == 2) return launch_wave<2, 2>(t, g, st);
+    if (n == 2 && m == 1) return launch_wave<2, 1>(t, g, st);
+    if (n == 1 && m == 1) return launch_wave<1, 1>(t, g, st);
+    return ZM_EUNSUPPORTED;
+}
+
+}  // namespace zm
