@@ -78,7 +78,7 @@ __device__ __forceinline__ void psd_project_lds(double* As, double* Vs, double* 
     wave_lds_sync();
     const bool pair_on = pr < (K >> 1);
     for (int sweep = 0; sweep < 20; ++sweep) {
-        bool rotated = false;
+        bool rotated = false, big = false;
         for (int r = 0; r < K - 1; ++r) {
             // round-robin pairing of K players: player K-1 stays, the others rotate (no modulo: one conditional subtract)
             int p, q;
@@ -100,7 +100,11 @@ __device__ __forceinline__ void psd_project_lds(double* As, double* Vs, double* 
             p = on ? p : 0;
             q = on ? q : 0;
             const double app = As[p * PLD + p], aqq = As[q * PLD + q], apq = As[p * PLD + q];
-            const bool rot = on && (apq * apq > 0x1p-104 * __builtin_fabs(app * aqq));
+            const double apq2 = apq * apq, dd = __builtin_fabs(app * aqq);
+            const bool rot = on && (apq2 > 0x1p-104 * dd);
+            // quadratic convergence: if every rotation of this sweep started from |a_pq| <= 2^-26 sqrt|a_pp a_qq|, the sweep
+            // leaves off-diagonals <= ~2^-52 relative -- the next sweep would rotate nothing and need not be run
+            big |= (__ballot(on && (apq2 > 0x1p-52 * dd)) != 0ull);
             double c = 1.0, s = 0.0;
             if (rot) {
                 // t = sgn(d) 2 a_pq / (|d| + sqrt(d^2 + 4 a_pq^2)),  d = a_qq - a_pp   (the smaller root of t^2 + 2 tau t - 1)
@@ -138,7 +142,7 @@ __device__ __forceinline__ void psd_project_lds(double* As, double* Vs, double* 
             }
             wave_lds_sync();
         }
-        if (!rotated) break;
+        if (!rotated || !big) break;
     }
     // A <- V max(w, eps) V^T   (the clamped eigenvalues are copied out of the diagonal first)
     if (lane < PK) cs[lane] = (lane < k) ? (As[lane * PLD + lane] > eps ? As[lane * PLD + lane] : eps) : 0.0;
