@@ -169,7 +169,6 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
                     Kcol[j] = Kcn[j];
                     Mrow[j] = Mrn[j];
                 }
-                (void)Krow;
             }
         }
         // ---- forward rollout, projection, dual update, residuals
@@ -228,8 +227,6 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
                     Kcol[j] = Kcn[j];
                     Mrow[j] = Mrn[j];
                 }
-                (void)Kcol;
-                (void)Mrow;
             }
         }
         nrp = row_max(nrp);
