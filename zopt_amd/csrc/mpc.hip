@@ -465,17 +465,28 @@ extern "C" int zm_mpc_solve_warm_f64(const double* A, const double* B, const dou
                                      int max_iter, int warm_start, double* workspace, double* xTraj, double* uTraj,
                                      int32_t* status, int32_t* iters, double* resid, int64_t batch, int N, int n, int m,
                                      void* stream) {
+    return zm_mpc_solve_adaptive_f64(A, B, K, Minv, 1, 0, 1.0, x_lb, x_ub, u_lb, u_ub, x0, rho, eps_abs, eps_rel, eps_prim_inf,
+                                     max_iter, warm_start, workspace, xTraj, uTraj, status, iters, resid, batch, N, n, m, stream);
+}
+
+extern "C" int zm_mpc_solve_adaptive_f64(const double* A, const double* B, const double* K, const double* Minv, int n_levels,
+                                         int level0, double rho_step, const double* x_lb, const double* x_ub,
+                                         const double* u_lb, const double* u_ub, const double* x0, double rho, double eps_abs,
+                                         double eps_rel, double eps_prim_inf, int max_iter, int warm_start, double* workspace,
+                                         double* xTraj, double* uTraj, int32_t* status, int32_t* iters, double* resid,
+                                         int64_t batch, int N, int n, int m, void* stream) {
     if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     if (!A || !B || !K || !Minv || !x_lb || !x_ub || !u_lb || !u_ub || !x0 || !workspace || !xTraj || !uTraj || !status)
         return zm::set_error(ZM_EINVAL, "zm_mpc_solve_f64: null pointer");
     if (batch < 0 || N < 1 || max_iter < 0 || !(rho > 0.0)) return zm::set_error(ZM_EINVAL, "zm_mpc_solve_f64: bad size");
-    if (batch == 0) return ZM_OK;
+    if (n_levels < 1 || level0 < 0 || level0 >= n_levels || (n_levels > 1 && !(rho_step > 1.0)))
+        return zm::set_error(ZM_EINVAL, "zm_mpc_solve_adaptive_f64: bad penalty levels");
     zm::MpcTabs t{A, B, K, Minv, x_lb, x_ub, u_lb, u_ub};
     zm::MpcArgs g{x0, rho, eps_abs, eps_rel, eps_prim_inf, max_iter, warm_start == 2 ? 2 : (warm_start ? 1 : 0), workspace, xTraj, uTraj, (int*)status, (int*)iters, resid,
-                  (long)batch, N};
+                  (long)batch, N, n_levels, level0, rho_step};
     hipStream_t st = (hipStream_t)stream;
     // default: 16 lanes per instance with the iterates in LDS (mpc_wave.hip); ZOPT_AMD_MPC_PATH=lane forces the
-    // lane-per-instance kernel below, which also takes the horizons that do not fit LDS
+    // lane-per-instance kernel below, which also takes the horizons that do not fit LDS (fixed penalty: level0 only)
     static const bool force_lane = [] {
         const char* e = getenv("ZOPT_AMD_MPC_PATH");
         return e && e[0] == 'l';
@@ -484,6 +495,8 @@ extern "C" int zm_mpc_solve_warm_f64(const double* A, const double* B, const dou
         const int rc = zm::mpc_wave_dispatch(t, g, n, m, st);
         if (rc != ZM_EUNSUPPORTED) return rc;
     }
+    t.K = K + (long)level0 * N * m * n;
+    t.Minv = Minv + (long)level0 * N * m * m;
     if (n == 12 && m == 4) return zm::launch_mpc<12, 4>(t, g, st);
     if (n == 8 && m == 4) return zm::launch_mpc<8, 4>(t, g, st);
     if (n == 4 && m == 2) return zm::launch_mpc<4, 2>(t, g, st);

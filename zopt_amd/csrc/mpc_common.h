@@ -14,6 +14,9 @@ struct MpcArgs {
     double* resid;
     long batch;
     int N;
+    // adaptive penalty (OSQP's adaptive_rho): tables for n_levels penalties rho * rho_step^(l - level0), level-major in K / Minv
+    int n_levels, level0;
+    double rho_step;
 };
 
 struct MpcTabs {

@@ -67,7 +67,8 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
     const bool live = inst_raw < g.batch;          // uniform over the 16-lane group
     const long inst = live ? inst_raw : g.batch - 1;   // idle groups shadow the last instance and never store
     const int N = g.N;
-    const double rho = g.rho;
+    double rho = g.rho;        // penalty of this group (changes with adaptive levels)
+    int lvl = g.level0;
     const bool sx = li < NS, su = li < MC;         // this lane owns a state / a control component
     const int ix = sx ? li : 0, iu = su ? li : 0;
     double* base = lds + (long)grp * N * WS_STAGE;
@@ -104,6 +105,13 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
     double* wsi = g.ws + inst * (4L * N * W);
     double* okflag = wsi + 2L * N * W + (long)N * MC;
     const bool warm = g.warm && (*okflag == 1.0);
+    if (warm && g.n_levels > 1) {   // the stored lam is scaled by the penalty the previous solve ended with
+        const int l = (int)okflag[1];
+        if (l >= 0 && l < g.n_levels) {
+            lvl = l;
+            rho = g.rho * pow(g.rho_step, (double)(lvl - g.level0));
+        }
+    }
     for (int k = 0; k < N; ++k) {
         const int ks = (g.warm == 2 && k + 1 < N) ? k + 1 : k;    // shifted warm start: iterate k <- iterate k+1
         const double wyx = warm ? wsi[(long)ks * W + ix] : 0.0, wlx = warm ? wsi[(long)N * W + (long)ks * W + ix] : 0.0;
@@ -121,8 +129,8 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
 
     // table rows / columns of one stage: K row (control lanes), K column (state lanes), Suu^-1 row (control lanes)
     auto load_tab = [&](const int k, double (&Krow)[NS], double (&Kcol)[MC], double (&Mrow)[MC]) {
-        const double* Kk = Ktab + (long)k * MC * NS;
-        const double* Mk = Mtab + (long)k * MC * MC;
+        const double* Kk = Ktab + ((long)lvl * N + k) * MC * NS;
+        const double* Mk = Mtab + ((long)lvl * N + k) * MC * MC;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             const double v = Kk[iu * NS + i];
@@ -250,6 +258,29 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
                 need_cert = chk;
             }
         }
+        // ---- adaptive penalty (OSQP adaptive_rho): rho <- rho sqrt(normalised primal / normalised dual residual), taken in
+        //      whole steps of the tabulated levels (factor rho_step, i.e. only when off by at least that factor); the scaled
+        //      dual lam = mu / rho is rescaled so that the unscaled multiplier mu is unchanged
+        if (g.n_levels > 1 && chk && !done) {
+            const double tiny = 1e-300;
+            const double rpn = rp / __builtin_fmax(__builtin_fmax(nw, ny), tiny);
+            const double rdn = rd / __builtin_fmax(rho * nl, tiny);
+            const double want = __builtin_sqrt(rpn / __builtin_fmax(rdn, tiny));
+            int dl = 0;
+            if (want == want && want > 0.0) dl = (int)(log(want) / log(g.rho_step));   // truncates toward 0
+            int nl_ = lvl + dl;
+            nl_ = nl_ < 0 ? 0 : (nl_ >= g.n_levels ? g.n_levels - 1 : nl_);
+            if (nl_ != lvl) {
+                const double rnew = g.rho * pow(g.rho_step, (double)(nl_ - g.level0));
+                const double sc = rho / rnew;
+                for (int k = 0; k < N; ++k) {
+                    lx[k * WS_STAGE] *= sc;
+                    if (su) lu[k * WS_STAGE] *= sc;
+                }
+                rho = rnew;
+                lvl = nl_;
+            }
+        }
         // ---- primal infeasibility certificate (mpc.hip header): adjoint sweep over r = w - y
         if (chk && __any(need_cert)) {
             sup = row_sum(sup);
@@ -298,6 +329,7 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
         if (li == 0) {
             g.status[inst] = status ? status : ZM_MPC_USER_LIMIT;
             *okflag = (status == ZM_MPC_OPTIMAL) ? 1.0 : 0.0;
+            okflag[1] = (double)lvl;
             if (g.iters) g.iters[inst] = it;
             if (g.resid) {
                 g.resid[inst * 2] = rp;

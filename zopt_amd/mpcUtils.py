@@ -56,21 +56,28 @@ class lqrMpc():
         # w-update Hessian (2Q + rho I, 2R + rho I) comparably conditioned
         self.rho = float(np.sqrt(max(np.trace(2 * self.Q) / self.n, 1e-12) * max(np.trace(2 * self.R) / self.m, 1e-12)))
 
-    def _device_problem(self, rho):
+    N_LEVELS, RHO_STEP = 7, 5.0      # adaptive penalty: rho * 5^(l - 3), l = 0..6  (OSQP changes rho only by factors >= 5)
+
+    def _device_problem(self, rho, adaptive):
         arr.require_gpu()
         if self._dev is None:
             self._dev = {k: arr.to_device(getattr(self, k), torch.float64)
                          for k in ("A", "B", "Q", "R", "Qf", "x_lb", "x_ub", "u_lb", "u_ub")}
-        if rho not in self._tables:
+        key = (rho, bool(adaptive))
+        if key not in self._tables:
             d = self._dev
-            K = torch.empty((self.N, self.m, self.n), dtype=torch.float64, device=d["A"].device)
-            Mi = torch.empty((self.N, self.m, self.m), dtype=torch.float64, device=d["A"].device)
-            rc = _lib.lib().zm_mpc_setup_f64(d["A"].data_ptr(), d["B"].data_ptr(), d["Q"].data_ptr(), d["R"].data_ptr(),
-                                             d["Qf"].data_ptr(), float(rho), self.N, self.n, self.m, K.data_ptr(),
-                                             Mi.data_ptr(), ctypes.c_void_p(arr.stream_ptr(K)))
-            _lib.check(rc, "lqrMpc setup")
-            self._tables[rho] = (K, Mi)
-        return self._dev, self._tables[rho]
+            nl = self.N_LEVELS if adaptive else 1
+            l0 = nl // 2
+            K = torch.empty((nl, self.N, self.m, self.n), dtype=torch.float64, device=d["A"].device)
+            Mi = torch.empty((nl, self.N, self.m, self.m), dtype=torch.float64, device=d["A"].device)
+            for l in range(nl):
+                rc = _lib.lib().zm_mpc_setup_f64(d["A"].data_ptr(), d["B"].data_ptr(), d["Q"].data_ptr(), d["R"].data_ptr(),
+                                                 d["Qf"].data_ptr(), float(rho) * self.RHO_STEP ** (l - l0), self.N, self.n,
+                                                 self.m, K[l].data_ptr(), Mi[l].data_ptr(),
+                                                 ctypes.c_void_p(arr.stream_ptr(K)))
+                _lib.check(rc, "lqrMpc setup")
+            self._tables[key] = (K, Mi, nl, l0)
+        return self._dev, self._tables[key]
 
     def solve(self, x0, **kwargs):
         """
@@ -81,7 +88,8 @@ class lqrMpc():
             x0 : Initial state (n,) -- or (..., n): a batch of independent instances
             **kwargs : solver options, named as the OSQP options the reference forwards through cvxpy
                 (demos/lqrMpc.py:32): eps_abs, eps_rel (default 1e-5, cvxpy's OSQP default), max_iter (default 10000),
-                rho, eps_prim_inf (default 1e-4), warm_start (default True, as cvxpy: a solve for the same batch shape
+                rho, adaptive_rho (default True: the penalty moves between 7 tabulated levels rho * 5^l as OSQP's does),
+                eps_prim_inf (default 1e-4), warm_start (default True, as cvxpy: a solve for the same batch shape
                 starts from the previous solve's ADMM iterates; `warm_start="shift"` (extension) advances them by one
                 horizon step first, the right guess inside the receding-horizon loop of demos/lqrMpc.py:41-48);
                 `solver` may be None or "OSQP" (the build has one solver); eps_dual_inf / verbose / polish are accepted
@@ -100,6 +108,7 @@ class lqrMpc():
         eps_rel = float(kwargs.pop("eps_rel", 1e-5))
         max_iter = int(kwargs.pop("max_iter", 10000))
         rho = float(kwargs.pop("rho", self.rho))
+        adaptive = bool(kwargs.pop("adaptive_rho", True))        # OSQP / cvxpy default
         eps_pinf = float(kwargs.pop("eps_prim_inf", 1e-4))
         warm = kwargs.pop("warm_start", kwargs.pop("warm_starting", True))
         shift = isinstance(warm, str) and warm == "shift"     # extension: previous iterates advanced by one horizon step
@@ -112,12 +121,12 @@ class lqrMpc():
         if len(shp) < 1 or shp[-1] != self.n:
             raise ValueError(f"x0 has shape {shp}, expected (..., {self.n})")
         lead = shp[:-1]
-        d, (K, Mi) = self._device_problem(rho)
+        d, (K, Mi, n_levels, level0) = self._device_problem(rho, adaptive)
         dx0 = arr.to_device(x0, torch.float64).reshape(-1, self.n).contiguous()
         Bn = dx0.shape[0]
         dev = dx0.device
         N, n, m = self.N, self.n, self.m
-        key = (Bn, str(dev), rho)
+        key = (Bn, str(dev), rho, adaptive)
         warm = warm and self._ws is not None and self._ws[0] == key
         if not warm:
             self._ws = (key, torch.empty(4 * Bn * N * (n + m), dtype=torch.float64, device=dev))
@@ -127,12 +136,12 @@ class lqrMpc():
         st = torch.empty(Bn, dtype=torch.int32, device=dev)
         its = torch.empty(Bn, dtype=torch.int32, device=dev)
         res = torch.empty((Bn, 2), dtype=torch.float64, device=dev)
-        rc = _lib.lib().zm_mpc_solve_warm_f64(d["A"].data_ptr(), d["B"].data_ptr(), K.data_ptr(), Mi.data_ptr(),
-                                              d["x_lb"].data_ptr(), d["x_ub"].data_ptr(), d["u_lb"].data_ptr(),
-                                              d["u_ub"].data_ptr(), dx0.data_ptr(), rho, eps_abs, eps_rel, eps_pinf,
-                                              max_iter, (2 if shift else 1) if warm else 0, ws.data_ptr(), xT.data_ptr(), uT.data_ptr(),
-                                              st.data_ptr(), its.data_ptr(), res.data_ptr(), Bn, N, n, m,
-                                              ctypes.c_void_p(arr.stream_ptr(dx0)))
+        rc = _lib.lib().zm_mpc_solve_adaptive_f64(d["A"].data_ptr(), d["B"].data_ptr(), K.data_ptr(), Mi.data_ptr(), n_levels,
+                                                  level0, self.RHO_STEP, d["x_lb"].data_ptr(), d["x_ub"].data_ptr(),
+                                                  d["u_lb"].data_ptr(), d["u_ub"].data_ptr(), dx0.data_ptr(), rho, eps_abs,
+                                                  eps_rel, eps_pinf, max_iter, (2 if shift else 1) if warm else 0,
+                                                  ws.data_ptr(), xT.data_ptr(), uT.data_ptr(), st.data_ptr(), its.data_ptr(),
+                                                  res.data_ptr(), Bn, N, n, m, ctypes.c_void_p(arr.stream_ptr(dx0)))
         _lib.check(rc, "lqrMpc.solve")
         self.last_iterations = its.reshape(lead).cpu().numpy()
         self.last_residuals = res.reshape(lead + (2,)).cpu().numpy()
