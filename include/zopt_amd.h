@@ -186,6 +186,17 @@ int zm_ddp_backward_f64(const double* f_x, const double* f_u, const double* f_xx
                         const double* vf_x, const double* vf_xx, const int32_t* active, int shared_hessian, double* l,
                         double* L, int64_t batch, int T, int n, int m, void* stream);
 
+/* The same sweeps, also returning the quadratic value function they end with -- what the reference's single-step helpers
+ * riccatiStep_ilqr (ilqrUtils.py:153-173) and riccatiStep_ddp (:184-206) return next to the policy (T = 1), and the value at the
+ * trajectory start for T > 1:   v' = (c + v) - 1/2 l^T Q_uu l,  v_x' = Q_x - L^T Q_uu l,  v_xx' = Q_xx - L^T Q_uu L   (:170).
+ * in : as zm_ilqr_backward_f64, plus c (batch,T) or NULL and vf (batch) or NULL (the scalar terms);
+ *      f_xx, f_ux, f_uu all NULL: iLQR step; all given: DDP step (PD-projected second-order dynamics terms)
+ * out: l, L as before;  v_out (batch), vx_out (batch,n), vxx_out (batch,n,n), each may be NULL */
+int zm_riccati_value_f64(const double* f_x, const double* f_u, const double* f_xx, const double* f_ux, const double* f_uu,
+                         const double* c, const double* c_x, const double* c_u, const double* c_xx, const double* c_ux,
+                         const double* c_uu, const double* vf, const double* vf_x, const double* vf_xx, double* l, double* L,
+                         double* v_out, double* vx_out, double* vxx_out, int64_t batch, int T, int n, int m, void* stream);
+
 /* Second-order expansion of a registered model along a trajectory (forward-mode hyper-dual numbers).
  * Replaces: zopt/pytrees.py:180-194 QuadraticDynamics.from_function / from_trajectory (jax.hessian of dynFun):
  * in : xTraj (batch,T+1,n)  uTraj (batch,T,m)  active or NULL

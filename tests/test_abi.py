@@ -55,10 +55,39 @@ def test_bad_arguments_return_codes_without_gpu():
 
 
 def test_python_surface_mirrors_reference_signatures():
-    """reference zopt/lqrUtils.py:144 `discreteFiniteHorizonLqr(A, B, Q, R, N)`, :266 proportionalFeedbackController."""
-    from zopt_amd import lqrUtils
-    assert list(inspect.signature(lqrUtils.discreteFiniteHorizonLqr).parameters) == ["A", "B", "Q", "R", "N"]
-    assert list(inspect.signature(lqrUtils.proportionalFeedbackController).parameters) == ["x", "x0", "u0", "K"]
+    """Same names and positional parameters as the reference modules, checked without a GPU:
+    lqrUtils.py:144, :176, :207, :266; ilqrUtils.py:33, :116, :176, :209, :217, :222, :254, :261, :331; mpcUtils.py:14, :61;
+    pytrees.py field orders and constructors."""
+    from zopt_amd import ilqrUtils, lqrUtils, mpcUtils, pytrees
+    params = lambda f: list(inspect.signature(f).parameters)
+    assert params(lqrUtils.discreteFiniteHorizonLqr) == ["A", "B", "Q", "R", "N"]
+    assert params(lqrUtils.discreteInfiniteHorizonLqr)[:4] == ["A", "B", "Q", "R"]
+    assert params(lqrUtils.bilinearAffineLqr) == ["A", "B", "d", "Q", "R", "H", "q", "r", "q0", "N"]
+    assert params(lqrUtils.proportionalFeedbackController) == ["x", "x0", "u0", "K"]
+    assert params(ilqrUtils.trajectoryRollout) == ["x0", "dynFun", "policy", "trajPrev", "alpha"]
+    assert params(ilqrUtils.forwardPass2) == ["x0", "dynFun", "costFun", "policy", "trajPrev"]
+    assert params(ilqrUtils.riccatiStep_ilqr) == ["dynamics", "cost", "value"]
+    assert params(ilqrUtils.riccatiStep_ddp) == ["dynamics", "cost", "value"]
+    assert params(ilqrUtils.backwardPass_ilqr) == ["dynamics", "cost", "Vf"]
+    assert params(ilqrUtils.backwardPass_ddp) == ["dynamics", "cost", "Vf"]
+    assert params(ilqrUtils.ensurePositiveDefinite) == ["a", "eps"]
+    assert params(ilqrUtils.conditionQuadraticCost) == ["quadratic_cost"]
+    assert params(ilqrUtils.conditionValueFunction) == ["Vf"]
+    sig = ["dynamics", "runningCost", "terminalCost", "x0", "uGuess", "maxIter", "tol"]
+    assert params(ilqrUtils.iterativeLqr) == sig and params(ilqrUtils.differentialDynamicProgramming) == sig
+    assert inspect.signature(ilqrUtils.iterativeLqr).parameters["maxIter"].default == 100
+    assert inspect.signature(ilqrUtils.iterativeLqr).parameters["tol"].default == 1e-3
+    assert params(mpcUtils.lqrMpc.__init__) == ["self", "A", "B", "Q", "R", "N", "x_lb", "x_ub", "u_lb", "u_ub", "Qf"]
+    assert params(mpcUtils.lqrMpc.solve) == ["self", "x0", "kwargs"]
+    assert pytrees.Trajectory._fields == ("xTraj", "uTraj")
+    assert pytrees.QuadraticValueFunction._fields == ("v", "v_x", "v_xx")
+    assert pytrees.QuadraticCostFunction._fields == ("c", "c_x", "c_u", "c_xx", "c_ux", "c_uu")
+    assert pytrees.AffineDynamics._fields == ("f", "f_x", "f_u")
+    assert pytrees.QuadraticDynamics._fields == ("f", "f_x", "f_u", "f_xx", "f_ux", "f_uu")
+    assert pytrees.AffinePolicy._fields == ("l", "L")
+    for cls in (pytrees.AffineDynamics, pytrees.QuadraticDynamics, pytrees.QuadraticCostFunction):
+        assert callable(cls.from_function) and callable(cls.from_trajectory)
+    assert callable(pytrees.QuadraticValueFunction.fromTerminalCostFunction)
 
 
 def test_product_never_imports_oracle():

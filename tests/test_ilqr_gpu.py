@@ -107,3 +107,55 @@ def test_pivoting_and_torch(ilqr):
     pol = ilqr.backwardPass_ilqr(t(dyn), t(cost), t(Vf))
     assert pol.L.is_cuda
     assert _rel(pol.L.cpu().numpy(), ref.L) <= 1e-9 and _rel(pol.l.cpu().numpy(), ref.l) <= 1e-9
+
+
+def test_riccatiStep_known_answers_and_value_function():
+    """reference tests/test_ilqrUtils.py:56-81 (riccatiStep_ilqr, exact ==) and :110-135 (riccatiStep_ddp, rel 1e-3):
+    the single-step helpers return the new value function next to the policy."""
+    from zopt_amd import ilqrUtils, pytrees
+    I, Z, z2 = np.eye(2), np.zeros((2, 2)), np.zeros(2)
+    dyn = pytrees.AffineDynamics(z2, I, I)
+    cost = pytrees.QuadraticCostFunction(0.0, z2, z2, I, Z, I)
+    val = pytrees.QuadraticValueFunction(0.0, z2, I)
+    V, pol = ilqrUtils.riccatiStep_ilqr(dyn, cost, val)
+    assert V.v == 0 and np.all(V.v_x == 0) and np.array_equal(V.v_xx, 1.5 * I)
+    assert np.all(pol.l == 0) and np.array_equal(pol.L, -0.5 * I)
+    zz = np.zeros((2, 2, 2))
+    V2, pol2 = ilqrUtils.riccatiStep_ddp(pytrees.QuadraticDynamics(z2, I, I, zz, zz, zz), cost, val)
+    assert V2.v == 0 and np.all(V2.v_x == 0)
+    assert V2.v_xx == pytest.approx(1.5 * I, rel=1e-3) and pol2.L == pytest.approx(-0.5 * I, rel=1e-3)
+    # random batched steps against the oracle's step functions (value function included)
+    rng = np.random.default_rng(17)
+    for n, m in ((12, 4), (5, 2), (8, 4)):
+        b = 6
+        f = rng.standard_normal((b, n))
+        f_x = rng.standard_normal((b, n, n)) * (0.9 / np.sqrt(n))
+        f_u = rng.standard_normal((b, n, m))
+        M = rng.standard_normal((b, n + m, n + m))
+        H = M @ np.swapaxes(M, -1, -2) / (n + m) + np.eye(n + m)
+        c_xx, c_ux, c_uu = H[:, :n, :n].copy(), H[:, n:, :n].copy(), H[:, n:, n:].copy()
+        c, c_x, c_u = rng.standard_normal(b), rng.standard_normal((b, n)), rng.standard_normal((b, m))
+        Mv = rng.standard_normal((b, n, n))
+        v, v_x, v_xx = rng.standard_normal(b), rng.standard_normal((b, n)), Mv @ np.swapaxes(Mv, -1, -2) / n + np.eye(n)
+        Vg, pg = ilqrUtils.riccatiStep_ilqr(pytrees.AffineDynamics(f, f_x, f_u),
+                                            pytrees.QuadraticCostFunction(c, c_x, c_u, c_xx, c_ux, c_uu),
+                                            pytrees.QuadraticValueFunction(v, v_x, v_xx))
+        f_xx, f_ux, f_uu = (0.1 * rng.standard_normal((b, n) + s_) for s_ in ((n, n), (m, n), (m, m)))
+        f_xx = 0.5 * (f_xx + np.swapaxes(f_xx, -1, -2))
+        f_uu = 0.5 * (f_uu + np.swapaxes(f_uu, -1, -2))
+        Vd, pd = ilqrUtils.riccatiStep_ddp(pytrees.QuadraticDynamics(f, f_x, f_u, f_xx, f_ux, f_uu),
+                                           pytrees.QuadraticCostFunction(c, c_x, c_u, c_xx, c_ux, c_uu),
+                                           pytrees.QuadraticValueFunction(v, v_x, v_xx))
+        for i in range(b):
+            Vr, pr = zo.riccatiStep_ilqr(zo.AffineDynamics(f[i], f_x[i], f_u[i]),
+                                         zo.QuadraticCostFunction(c[i], c_x[i], c_u[i], c_xx[i], c_ux[i], c_uu[i]),
+                                         zo.QuadraticValueFunction(v[i], v_x[i], v_xx[i]))
+            assert abs(Vg.v[i] - Vr.v) <= 1e-10 * max(1.0, abs(Vr.v))
+            assert _rel(Vg.v_x[i], Vr.v_x) <= 1e-10 and _rel(Vg.v_xx[i], Vr.v_xx) <= 1e-10
+            assert _rel(pg.l[i], pr.l) <= 1e-10 and _rel(pg.L[i], pr.L) <= 1e-10
+            Vr, pr = zo.riccatiStep_ddp(zo.QuadraticDynamics(f[i], f_x[i], f_u[i], f_xx[i], f_ux[i], f_uu[i]),
+                                        zo.QuadraticCostFunction(c[i], c_x[i], c_u[i], c_xx[i], c_ux[i], c_uu[i]),
+                                        zo.QuadraticValueFunction(v[i], v_x[i], v_xx[i]))
+            assert abs(Vd.v[i] - Vr.v) <= 1e-9 * max(1.0, abs(Vr.v))
+            assert _rel(Vd.v_x[i], Vr.v_x) <= 1e-9 and _rel(Vd.v_xx[i], Vr.v_xx) <= 1e-9
+            assert _rel(pd.l[i], pr.l) <= 1e-9 and _rel(pd.L[i], pr.L) <= 1e-9

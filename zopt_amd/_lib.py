@@ -61,6 +61,8 @@ SYMBOLS = {
     "zm_mpc_solve_warm_f64": (ctypes.c_int, [_c_dp] * 9 + [ctypes.c_double] * 4 + [ctypes.c_int] * 2 + [_c_dp] * 6 +
                               [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     # (f_x, f_u, f_xx, f_ux, f_uu, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, active, shared_hessian, l, L, batch, T, n, m, stream)
+    "zm_riccati_value_f64": (ctypes.c_int, [_c_dp] * 19 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                           ctypes.c_void_p]),
     "zm_ddp_backward_f64": (ctypes.c_int, [_c_dp] * 13 + [ctypes.c_int] + [_c_dp] * 2 +
                             [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     # (model*, xTraj, uTraj, active, f_xx, f_ux, f_uu, batch, T, stream)

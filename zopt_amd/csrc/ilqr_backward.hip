@@ -66,6 +66,7 @@ struct IlqrAddr {
     int dF, dC, sF, sC, sCu, scv, sOut, sd;
     bool rowok[KS], vF[KS], vC[KS], vCu, vcv, vOut, vL, cA;
     bool warm_v = false;   // MODE 2: the Jacobi eigenvector buffer holds the previous step's result
+    double vsum = 0.0;     // MODE 0/2, lanes c == NP: sum over the steps of -1/2 l^T Q_uu l  (scalar part of the value function)
     double cu_pad;
 };
 
@@ -238,6 +239,10 @@ __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], 
     if (a.vOut) *a.pOut = out;
     a.pOut -= a.sOut;
     const double lv = a.vL ? out : 0.0;
+    if constexpr (MODE != 1) {
+        // -1/2 l^T Q_uu l with l = -x, Q_uu x = Q_u  (ilqrUtils.py:170 / :203), on the lanes that solved for l
+        if (c == NP) a.vsum -= 0.5 * ((x[0] * qu[0] + x[1] * qu[1]) + (x[2] * qu[2] + x[3] * qu[3]));
+    }
 
     double vxn = qv;
     if constexpr (MODE == 1) {
@@ -276,7 +281,9 @@ __global__ __launch_bounds__(64, 2) void ilqr_backward_t16_f64(
     const double* __restrict__ c_uu, const double* __restrict__ vf_x, const double* __restrict__ vf_xx,
     const double* __restrict__ dvec, const double* __restrict__ f_xx, const double* __restrict__ f_ux,
     const double* __restrict__ f_uu, const long svx, const long svxx, const int* __restrict__ active,
-    const int shared_h, double* __restrict__ lout, double* __restrict__ Lout, const int T, const int n, const int m) {
+    const int shared_h, double* __restrict__ lout, double* __restrict__ Lout, const int T, const int n, const int m,
+    const double* __restrict__ c_s, const double* __restrict__ vf_s, double* __restrict__ v_out,
+    double* __restrict__ vx_out, double* __restrict__ vxx_out) {
     constexpr int NP = 4 * KS;
     const int lane = threadIdx.x;
     const long traj = blockIdx.x;
@@ -409,6 +416,23 @@ __global__ __launch_bounds__(64, 2) void ilqr_backward_t16_f64(
     } else {
         ilqr_step<KS, MODE, false>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, jA, jV, jcs, jpq, n, m);
     }
+    // optional: the value function the sweep ends with (riccatiStep_ilqr / _ddp return it: ilqrUtils.py:170, :203)
+    if (vxx_out) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int row = 4 * s + g;
+            if (row < n && cA) vxx_out[traj * nn + row * n + c] = Vxx[s];
+        }
+    }
+    if (vx_out && g == 0 && cA) vx_out[traj * n + c] = sm[80 + c];
+    if (v_out) {
+        double cs = 0.0;   // sum_k c_k
+        if (c_s)
+            for (int k2 = lane; k2 < T; k2 += 64) cs += c_s[traj * T + k2];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cs += __shfl_xor(cs, off, 64);
+        if (g == 0 && c == NP) v_out[traj] = ((vf_s ? vf_s[traj] : 0.0) + cs) + a.vsum;
+    }
 }
 
 }  // namespace zm
@@ -417,22 +441,27 @@ namespace zm {
 struct DdpTensors {
     const double *f_xx, *f_ux, *f_uu;
 };
+struct ValueIO {   // optional scalar inputs / value-function outputs
+    const double *c, *vf;
+    double *v_out, *vx_out, *vxx_out;
+};
 
 template <int MODE>
 static int launch_ilqr(const double* f_x, const double* f_u, const double* c_x, const double* c_u, const double* c_xx,
                        const double* c_ux, const double* c_uu, const double* vf_x, const double* vf_xx, const double* d,
                        long svx, long svxx, const int* act, int sh, double* l, double* L, int64_t batch, int T, int n, int m,
-                       hipStream_t st, DdpTensors z = DdpTensors{nullptr, nullptr, nullptr}) {
+                       hipStream_t st, DdpTensors z = DdpTensors{nullptr, nullptr, nullptr},
+                       ValueIO v = ValueIO{nullptr, nullptr, nullptr, nullptr, nullptr}) {
     const dim3 grid((unsigned)batch), block(64);
     if (n <= 4)
         hipLaunchKernelGGL((ilqr_backward_t16_f64<1, MODE>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
-                           vf_xx, d, z.f_xx, z.f_ux, z.f_uu, svx, svxx, act, sh, l, L, T, n, m);
+                           vf_xx, d, z.f_xx, z.f_ux, z.f_uu, svx, svxx, act, sh, l, L, T, n, m, v.c, v.vf, v.v_out, v.vx_out, v.vxx_out);
     else if (n <= 8)
         hipLaunchKernelGGL((ilqr_backward_t16_f64<2, MODE>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
-                           vf_xx, d, z.f_xx, z.f_ux, z.f_uu, svx, svxx, act, sh, l, L, T, n, m);
+                           vf_xx, d, z.f_xx, z.f_ux, z.f_uu, svx, svxx, act, sh, l, L, T, n, m, v.c, v.vf, v.v_out, v.vx_out, v.vxx_out);
     else
         hipLaunchKernelGGL((ilqr_backward_t16_f64<3, MODE>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
-                           vf_xx, d, z.f_xx, z.f_ux, z.f_uu, svx, svxx, act, sh, l, L, T, n, m);
+                           vf_xx, d, z.f_xx, z.f_ux, z.f_uu, svx, svxx, act, sh, l, L, T, n, m, v.c, v.vf, v.v_out, v.vx_out, v.vxx_out);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }
@@ -501,4 +530,24 @@ extern "C" int zm_ddp_backward_f64(const double* f_x, const double* f_u, const d
     return zm::launch_ilqr<2>(f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, (long)n, (long)n * n,
                               (const int*)active, shared_hessian ? 1 : 0, l, L, batch, T, n, m, (hipStream_t)stream,
                               zm::DdpTensors{f_xx, f_ux, f_uu});
+}
+
+extern "C" int zm_riccati_value_f64(const double* f_x, const double* f_u, const double* f_xx, const double* f_ux,
+                                    const double* f_uu, const double* c, const double* c_x, const double* c_u,
+                                    const double* c_xx, const double* c_ux, const double* c_uu, const double* vf,
+                                    const double* vf_x, const double* vf_xx, double* l, double* L, double* v_out,
+                                    double* vx_out, double* vxx_out, int64_t batch, int T, int n, int m, void* stream) {
+    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
+    if (!f_x || !f_u || !c_x || !c_u || !c_xx || !c_ux || !c_uu || !vf_x || !vf_xx || !l || !L)
+        return zm::set_error(ZM_EINVAL, "zm_riccati_value_f64: null pointer");
+    const bool ddp = f_xx || f_ux || f_uu;
+    if (ddp && (!f_xx || !f_ux || !f_uu)) return zm::set_error(ZM_EINVAL, "zm_riccati_value_f64: f_xx, f_ux, f_uu go together");
+    const int rc = zm_check_sweep_args("zm_riccati_value_f64", batch, T, n, m);
+    if (rc) return rc;
+    const zm::ValueIO v{c, vf, v_out, vx_out, vxx_out};
+    if (ddp)
+        return zm::launch_ilqr<2>(f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, (long)n, (long)n * n, nullptr, 0, l,
+                                  L, batch, T, n, m, (hipStream_t)stream, zm::DdpTensors{f_xx, f_ux, f_uu}, v);
+    return zm::launch_ilqr<0>(f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, (long)n, (long)n * n, nullptr, 0, l, L,
+                              batch, T, n, m, (hipStream_t)stream, zm::DdpTensors{nullptr, nullptr, nullptr}, v);
 }

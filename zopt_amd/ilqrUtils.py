@@ -74,6 +74,66 @@ def backwardPass_ilqr(dynamics, cost, Vf):
     return AffinePolicy(arr.result_like(dl, template), arr.result_like(dL, template))
 
 
+def _riccati_step(dynamics, cost, value, ddp):
+    """One backward step with the value function returned (zm_riccati_value_f64, T = 1)."""
+    dyn = _fields(dynamics)
+    f_x, f_u = dyn[1], dyn[2]
+    c, c_x, c_u, c_xx, c_ux, c_uu = _fields(cost)
+    v, v_x, v_xx = _fields(value)
+    shp = _shape(f_u)
+    if len(shp) < 2:
+        raise ValueError("f_u must have shape (..., n, m)")
+    lead, (n, m) = shp[:-2], shp[-2:]
+    expect = {"f_x": (f_x, lead + (n, n)), "c": (c, lead), "c_x": (c_x, lead + (n,)), "c_u": (c_u, lead + (m,)),
+              "c_xx": (c_xx, lead + (n, n)), "c_ux": (c_ux, lead + (m, n)), "c_uu": (c_uu, lead + (m, m)),
+              "v": (v, lead), "v_x": (v_x, lead + (n,)), "v_xx": (v_xx, lead + (n, n))}
+    if ddp:
+        expect.update({"f_xx": (dyn[3], lead + (n, n, n)), "f_ux": (dyn[4], lead + (n, m, n)), "f_uu": (dyn[5], lead + (n, m, m))})
+    for name, (X, s_) in expect.items():
+        if _shape(X) != s_:
+            raise ValueError(f"{name} has shape {_shape(X)}, expected {s_}")
+    template = f_x
+    dt = torch.float64
+    T = lambda X: arr.to_device(X, dt).contiguous()
+    df_x, df_u, dc, dc_x, dc_u, dc_xx, dc_ux, dc_uu, dv, dv_x, dv_xx = (T(X) for X in (f_x, f_u, c, c_x, c_u, c_xx, c_ux, c_uu, v,
+                                                                                         v_x, v_xx))
+    z = [T(X).data_ptr() for X in dyn[3:6]] if ddp else [None, None, None]
+    zk = [T(X) for X in dyn[3:6]] if ddp else []          # keep alive
+    if ddp:
+        z = [t.data_ptr() for t in zk]
+    batch = 1
+    for d in lead:
+        batch *= int(d)
+    dev = df_x.device
+    dl = torch.empty(lead + (m,), dtype=dt, device=dev)
+    dL = torch.empty(lead + (m, n), dtype=dt, device=dev)
+    ov = torch.empty(lead, dtype=dt, device=dev)
+    ovx = torch.empty(lead + (n,), dtype=dt, device=dev)
+    ovxx = torch.empty(lead + (n, n), dtype=dt, device=dev)
+    rc = _lib.lib().zm_riccati_value_f64(df_x.data_ptr(), df_u.data_ptr(), z[0], z[1], z[2], dc.data_ptr(), dc_x.data_ptr(),
+                                         dc_u.data_ptr(), dc_xx.data_ptr(), dc_ux.data_ptr(), dc_uu.data_ptr(), dv.data_ptr(),
+                                         dv_x.data_ptr(), dv_xx.data_ptr(), dl.data_ptr(), dL.data_ptr(), ov.data_ptr(),
+                                         ovx.data_ptr(), ovxx.data_ptr(), batch, 1, n, m, ctypes.c_void_p(arr.stream_ptr(df_x)))
+    _lib.check(rc, "riccatiStep")
+    outs = [arr.result_like(o, template) for o in (ov, ovx, ovxx, dl, dL)]
+    if not arr.is_torch(template) and len(lead) == 0:
+        outs[0] = float(outs[0])
+    return QuadraticValueFunction(*outs[:3]), AffinePolicy(*outs[3:])
+
+
+def riccatiStep_ilqr(dynamics, cost, value):
+    """One step of the iLQR Riccati recursion (reference ilqrUtils.py:153-173): AffineDynamics (f (n), f_x (n,n), f_u (n,m)),
+    QuadraticCostFunction and QuadraticValueFunction of ONE time step (optionally with leading batch axes) ->
+    (QuadraticValueFunction(v', v_x', v_xx'), AffinePolicy(l, L))."""
+    return _riccati_step(dynamics, cost, value, ddp=False)
+
+
+def riccatiStep_ddp(dynamics, cost, value):
+    """One step of the DDP Riccati recursion (reference ilqrUtils.py:184-206): as riccatiStep_ilqr with QuadraticDynamics
+    (f, f_x, f_u, f_xx (n,n,n), f_ux (n,m,n), f_uu (n,m,m)); the second-order terms are PD-projected (:237-251)."""
+    return _riccati_step(dynamics, cost, value, ddp=True)
+
+
 LINESEARCH_ALPHAS = 0.5 ** np.arange(16)   # reference ilqrUtils.py:145
 
 
