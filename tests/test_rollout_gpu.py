@@ -171,3 +171,19 @@ def test_unregistered_callable_is_rejected(mods):
     with pytest.raises(TypeError):
         ilqr.trajectoryRollout(np.zeros(1), lambda x, u: x + u, pt.AffinePolicy(np.zeros((1, 1)), np.zeros((1, 1, 1))),
                                pt.Trajectory(np.zeros((2, 1)), np.zeros((1, 1))))
+
+
+def test_cost_function_call_matches_reference_definition():
+    """CostFunction.__call__ (pytrees.py:40-55): J = terminalCost(x_N) + sum runningCost(x_k, u_k); index k -> one running cost."""
+    from zopt_amd import models, pytrees
+    rng = np.random.default_rng(21)
+    Q, R, Qf = rng.standard_normal((12, 12)), rng.standard_normal((4, 4)), rng.standard_normal((12, 12))
+    cost = models.QuadraticCost(Q, R, Qf)
+    xT, uT = rng.standard_normal((3, 8, 12)), rng.standard_normal((3, 7, 4))
+    J = cost(pytrees.Trajectory(xT, uT))
+    ref = np.array([sum(xT[b, k] @ Q @ xT[b, k] + uT[b, k] @ R @ uT[b, k] for k in range(7)) + xT[b, -1] @ Qf @ xT[b, -1]
+                    for b in range(3)])
+    assert J.shape == (3,) and np.max(np.abs(J - ref)) <= 1e-11 * np.max(np.abs(ref))
+    j2 = cost(pytrees.Trajectory(xT[1], uT[1]), k=2)
+    assert abs(j2 - (xT[1, 2] @ Q @ xT[1, 2] + uT[1, 2] @ R @ uT[1, 2])) <= 1e-12
+    assert isinstance(cost(pytrees.Trajectory(xT[0], uT[0])), float)

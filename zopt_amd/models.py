@@ -75,6 +75,19 @@ class QuadraticCost:
             raise ValueError("QuadraticCost: Q (n,n), R (m,m), Qf (n,n) expected")
         self._dev = None
 
+    def __call__(self, traj, k=None):
+        """Cost of a trajectory, J = terminalCost(x_N) + sum_k runningCost(x_k, u_k) -- CostFunction.__call__ of the reference
+        (pytrees.py:40-55); with `k`, the running cost at step k only.  Leading batch axes allowed; evaluated on the GPU."""
+        from .pytrees import _expand
+        c, _, _, _, _, _ = _expand("cost", self, traj[0] if not hasattr(traj, "xTraj") else traj.xTraj,
+                                   traj[1] if not hasattr(traj, "uTraj") else traj.uTraj)
+        if k is not None:
+            return c[..., k]
+        xT = traj.xTraj if hasattr(traj, "xTraj") else traj[0]
+        v, _, _ = _expand("terminal", self, xT[..., -2:, :], None)
+        J = c.sum(-1) + v[..., 0]
+        return float(J) if (not hasattr(J, "device") and getattr(J, "ndim", 1) == 0) else J
+
     def runningCost(self, x, u):
         return x @ self.Q @ x + u @ self.R @ u
 
