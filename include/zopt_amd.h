@@ -218,6 +218,14 @@ int zm_psd_project_f64(double* A, int64_t count, int k, double eps, void* stream
 int zm_condition_cost_f64(double* c_xx, double* c_ux, double* c_uu, int64_t count, int n, int m, double eps,
                           void* stream);
 
+/* Second-order dynamics terms of the DDP step, PD-conditioned.
+ * Replaces: zopt/ilqrUtils.py:237-251 conditionQuadraticDynamics(quadratic_dynamics, v_x):
+ *     vf_.. = einsum('i,ijk', v_x, f_..);  [[vf_xx, vf_ux^T],[vf_ux, vf_uu]] <- ensurePositiveDefinite(.);  blocks sliced back
+ * in : f_xx (count,n,n,n)  f_ux (count,n,m,n)  f_uu (count,n,m,m)  v_x (count,n)
+ * out: vf_xx (count,n,n)  vf_ux (count,m,n)  vf_uu (count,m,m) */
+int zm_condition_dynamics_f64(const double* f_xx, const double* f_ux, const double* f_uu, const double* v_x, double* vf_xx,
+                              double* vf_ux, double* vf_uu, int64_t count, int n, int m, double eps, void* stream);
+
 /* ---- box-constrained LQ-MPC (reference: zopt/mpcUtils.py:12-81, class lqrMpc; the reference hands this QP to
  *      cvxpy -> OSQP, whose arithmetic is not in the reference tree: numeric parity is "unpinned", acceptance is by KKT
  *      residuals -- see DESIGN.md) -------------------------------------------------------------------------------

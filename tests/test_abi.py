@@ -73,6 +73,7 @@ def test_python_surface_mirrors_reference_signatures():
     assert params(ilqrUtils.ensurePositiveDefinite) == ["a", "eps"]
     assert params(ilqrUtils.conditionQuadraticCost) == ["quadratic_cost"]
     assert params(ilqrUtils.conditionValueFunction) == ["Vf"]
+    assert params(ilqrUtils.conditionQuadraticDynamics) == ["quadratic_dynamics", "v_x"]
     sig = ["dynamics", "runningCost", "terminalCost", "x0", "uGuess", "maxIter", "tol"]
     assert params(ilqrUtils.iterativeLqr) == sig and params(ilqrUtils.differentialDynamicProgramming) == sig
     assert inspect.signature(ilqrUtils.iterativeLqr).parameters["maxIter"].default == 100

@@ -116,3 +116,24 @@ def test_ddp_quadcopter_demo_problem(mods):
         assert bool(converged[i]) == rc
         assert J[i] == pytest.approx(rJ, rel=1e-7)
         assert _rel(traj.xTraj[i], rt.xTraj) <= 1e-6 and _rel(traj.uTraj[i], rt.uTraj) <= 1e-6 and _rel(L[i], rL) <= 1e-5
+
+
+def test_conditionQuadraticDynamics_matches_oracle():
+    """ilqrUtils.py:237-251: contraction with v_x, PD projection of the stacked block, blocks sliced back."""
+    from zopt_amd import ilqrUtils, pytrees
+    rng = np.random.default_rng(33)
+    for n, m, lead in ((12, 4, (5,)), (3, 2, (2, 4)), (7, 1, ())):
+        f_xx = rng.standard_normal(lead + (n, n, n))
+        f_xx = 0.5 * (f_xx + np.swapaxes(f_xx, -1, -2))
+        f_uu = rng.standard_normal(lead + (n, m, m))
+        f_uu = 0.5 * (f_uu + np.swapaxes(f_uu, -1, -2))
+        f_ux = rng.standard_normal(lead + (n, m, n))
+        v_x = rng.standard_normal(lead + (n,))
+        z = np.zeros(lead + (n,))
+        dyn = pytrees.QuadraticDynamics(z, np.zeros(lead + (n, n)), np.zeros(lead + (n, m)), f_xx, f_ux, f_uu)
+        gxx, gux, guu = ilqrUtils.conditionQuadraticDynamics(dyn, v_x)
+        rxx, rux, ruu = zo.conditionQuadraticDynamics(zo.QuadraticDynamics(*dyn), v_x)
+        assert gxx.shape == lead + (n, n) and gux.shape == lead + (m, n) and guu.shape == lead + (m, m)
+        sc = max(np.max(np.abs(rxx)), 1.0)
+        assert np.max(np.abs(gxx - rxx)) <= 1e-10 * sc and np.max(np.abs(gux - rux)) <= 1e-10 * sc
+        assert np.max(np.abs(guu - ruu)) <= 1e-10 * sc

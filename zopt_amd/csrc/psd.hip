@@ -42,6 +42,43 @@ struct StackedCost {  // [[c_xx, c_ux^T],[c_ux, c_uu]]   (ilqrUtils.py:230)
     }
 };
 
+// vf_zz = sum_l v_x[l] * d2f_l/dz2, stacked as [[vf_xx, vf_ux^T],[vf_ux, vf_uu]]   (ilqrUtils.py:240-247); the projected blocks go
+// to separate outputs (:249)
+struct ContractedDynamics {
+    const double *f_xx, *f_ux, *f_uu, *v_x;
+    double *o_xx, *o_ux, *o_uu;
+    int n, m;
+    __device__ __forceinline__ double load(long mat, int i, int j) const {
+        const double* vx = v_x + mat * n;
+        const double* p;
+        long st;
+        if (i < n && j < n) {
+            p = f_xx + mat * (long)n * n * n + (long)i * n + j;
+            st = (long)n * n;
+        } else if (i >= n && j >= n) {
+            p = f_uu + mat * (long)n * m * m + (long)(i - n) * m + (j - n);
+            st = (long)m * m;
+        } else {
+            const int u = (i >= n) ? i - n : j - n, x = (i >= n) ? j : i;   // f_ux[l][u][x], also under the transposed block
+            p = f_ux + mat * (long)n * m * n + (long)u * n + x;
+            st = (long)m * n;
+        }
+        double acc = 0.0;
+        for (int l = 0; l < n; ++l) acc = __builtin_fma(vx[l], p[l * st], acc);
+        return acc;
+    }
+    __device__ __forceinline__ void store(long mat, int i, int j, double v) const {
+        if (i < n) {
+            if (j < n) o_xx[(mat * n + i) * n + j] = v;
+        } else {
+            if (j < n)
+                o_ux[(mat * m + (i - n)) * n + j] = v;
+            else
+                o_uu[(mat * m + (i - n)) * m + (j - n)] = v;
+        }
+    }
+};
+
 template <class Mat>
 __global__ __launch_bounds__(64) void psd_project_kernel(const Mat M, const int k, const double eps, const long count) {
     __shared__ double As[PK * PLD], Vs[PK * PLD], cs[PK];
@@ -82,6 +119,20 @@ extern "C" int zm_condition_cost_f64(double* c_xx, double* c_ux, double* c_uu, i
     if (count == 0) return ZM_OK;
     hipLaunchKernelGGL((zm::psd_project_kernel<zm::StackedCost>), dim3((unsigned)count), dim3(64), 0, (hipStream_t)stream,
                        zm::StackedCost{c_xx, c_ux, c_uu, n, m}, n + m, eps, (long)count);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+
+extern "C" int zm_condition_dynamics_f64(const double* f_xx, const double* f_ux, const double* f_uu, const double* v_x,
+                                         double* vf_xx, double* vf_ux, double* vf_uu, int64_t count, int n, int m, double eps,
+                                         void* stream) {
+    if (count == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
+    if (!f_xx || !f_ux || !f_uu || !v_x || !vf_xx || !vf_ux || !vf_uu)
+        return zm::set_error(ZM_EINVAL, "zm_condition_dynamics_f64: null pointer");
+    if (count < 0 || n < 1 || m < 1) return zm::set_error(ZM_EINVAL, "zm_condition_dynamics_f64: bad size");
+    if (n + m > zm::PK) return zm::set_error(ZM_EUNSUPPORTED, "zm_condition_dynamics_f64: n+m=%d > 16", n + m);
+    hipLaunchKernelGGL((zm::psd_project_kernel<zm::ContractedDynamics>), dim3((unsigned)count), dim3(64), 0, (hipStream_t)stream,
+                       zm::ContractedDynamics{f_xx, f_ux, f_uu, v_x, vf_xx, vf_ux, vf_uu, n, m}, n + m, eps, (long)count);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }

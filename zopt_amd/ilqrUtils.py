@@ -234,6 +234,33 @@ def conditionValueFunction(Vf):
     return QuadraticValueFunction(v, v_x, ensurePositiveDefinite(v_xx))
 
 
+def conditionQuadraticDynamics(quadratic_dynamics, v_x):
+    """Ensure the quadratic terms of the DDP riccati step are positive definite (reference ilqrUtils.py:237-251):
+    `vf_.. = einsum('i,ijk', v_x, f_..)`, the stacked `[[vf_xx, vf_ux^T],[vf_ux, vf_uu]]` PD-projected, blocks returned as
+    `(vf_xx (..., n, n), vf_ux (..., m, n), vf_uu (..., m, m))`.  One time step or any leading batch / time axes."""
+    dyn = _fields(quadratic_dynamics)
+    f_xx, f_ux, f_uu = dyn[3], dyn[4], dyn[5]
+    shp = _shape(f_ux)
+    if len(shp) < 3:
+        raise ValueError("f_ux must have shape (..., n, m, n)")
+    lead, (n, m, n2) = shp[:-3], shp[-3:]
+    if n2 != n or _shape(f_xx) != lead + (n, n, n) or _shape(f_uu) != lead + (n, m, m) or _shape(v_x) != lead + (n,):
+        raise ValueError("conditionQuadraticDynamics: inconsistent shapes")
+    dt = torch.float64
+    dxx, dux, duu, dvx = (arr.to_device(X, dt).contiguous() for X in (f_xx, f_ux, f_uu, v_x))
+    count = 1
+    for d in lead:
+        count *= int(d)
+    oxx = torch.empty(lead + (n, n), dtype=dt, device=dxx.device)
+    oux = torch.empty(lead + (m, n), dtype=dt, device=dxx.device)
+    ouu = torch.empty(lead + (m, m), dtype=dt, device=dxx.device)
+    rc = _lib.lib().zm_condition_dynamics_f64(dxx.data_ptr(), dux.data_ptr(), duu.data_ptr(), dvx.data_ptr(), oxx.data_ptr(),
+                                              oux.data_ptr(), ouu.data_ptr(), count, n, m, 1e-3,
+                                              ctypes.c_void_p(arr.stream_ptr(dxx)))
+    _lib.check(rc, "conditionQuadraticDynamics")
+    return tuple(arr.result_like(o, f_xx) for o in (oxx, oux, ouu))
+
+
 def _registered_cost(runningCost, terminalCost):
     """Accepts a zopt_amd.models.QuadraticCost handle (for both arguments) or its bound methods."""
     for c in (runningCost, getattr(runningCost, "__self__", None)):
