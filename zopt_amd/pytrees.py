@@ -227,3 +227,14 @@ class AffinePolicy(NamedTuple):
 
     def __getitem__(self, k):
         return _slice(self, k)
+
+
+class QuadraticDeltaCost(NamedTuple):
+    """(dJ_lin, dJ_quad):  dJ_exp(alpha) = alpha * (dJ_lin + alpha * dJ_quad)   (reference pytrees.py:226-236; only its unused
+    `forwardPass` line search consumes it)"""
+    dJ_lin: object
+    dJ_quad: object
+
+    def __call__(self, alpha):
+        dJ_lin, dJ_quad = tuple.__iter__(self)
+        return alpha * (dJ_lin + alpha * dJ_quad)
