@@ -88,8 +88,8 @@ def cpu_baseline(batch, T, n, m, target_seconds=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU (weak scaling)")
     ap.add_argument("--T", type=int, default=50)
     ap.add_argument("--n", type=int, default=12)
