@@ -142,6 +142,13 @@ int zm_rollout_linesearch_list_f64(const zm_model_t* model, const zm_quadcost_t*
                                    int n_alpha, const int32_t* list, int64_t count, double* xTraj, double* uTraj, double* J,
                                    int32_t* alpha_idx, int64_t batch, int T, void* stream);
 
+/* Acceptance step of the iLQR / DDP loop (zopt/ilqrUtils.py:316-320) for the trajectories in list[0..count):
+ *     converged = |J - Jn| <= tol;  J <- Jn;  xTraj <- xTrajNew;  uTraj <- uTrajNew;  active <- !converged
+ * Arrays keep their (batch, ...) shapes; rows of trajectories not listed are left untouched. */
+int zm_ilqr_accept_f64(const int32_t* list, int64_t count, double* J, const double* Jn, double* xTraj, const double* xTrajNew,
+                       double* uTraj, const double* uTrajNew, int32_t* converged, int32_t* active, double tol, int64_t batch,
+                       int T, int n, int m, void* stream);
+
 /* First-order expansion of a registered model along a trajectory.
  * Replaces: zopt/pytrees.py:139-153 AffineDynamics.from_function / from_trajectory (jax.jacobian of dynFun at
  *           (xTraj[:-1], uTraj)):  f = dynFun(x_k,u_k), f_x = d dynFun/dx, f_u = d dynFun/du.

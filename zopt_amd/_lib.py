@@ -40,6 +40,8 @@ SYMBOLS = {
                                   [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "zm_rollout_linesearch_list_f64": (ctypes.c_int, [_c_dp] * 8 + [ctypes.c_int] + [_c_dp] + [ctypes.c_int64] + [_c_dp] * 4 +
                                        [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "zm_ilqr_accept_f64": (ctypes.c_int, [_c_dp, ctypes.c_int64] + [_c_dp] * 8 + [ctypes.c_double, ctypes.c_int64, ctypes.c_int,
+                                                                           ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     # (model*, xTraj, uTraj, active, f, f_x, f_u, batch, T, stream)
     "zm_linearize_dynamics_f64": (ctypes.c_int, [_c_dp] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     # (cost*, n, m, xTraj, uTraj, active, c, c_x, c_u, v, v_x, c_xx, c_ux, c_uu, v_xx, batch, T, stream)

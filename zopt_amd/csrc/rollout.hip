@@ -210,3 +210,45 @@ extern "C" int zm_rollout_linesearch_list_f64(const zm_model_t* model, const zm_
     return rollout_impl(model, cost, x0, l, L, xPrev, uPrev, alphas, n_alpha, nullptr, list, count, xTraj, uTraj, J, alpha_idx,
                         batch, T, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Acceptance step of the iLQR / DDP loop for the trajectories of a compacted id list: take the line search's result
+// (trajectory, cost), test convergence and retire converged trajectories.  Replaces zopt/ilqrUtils.py:316-320
+//     converged = abs(J - J_new) <= tol;  traj, J = traj_new, J_new
+// One block per listed trajectory; only those rows are touched (a masked whole-array update would move the entire batch
+// every iteration although most of it has converged).
+namespace zm {
+__global__ __launch_bounds__(256) void ilqr_accept_kernel(const int* __restrict__ list, const long count,
+                                                          double* __restrict__ J, const double* __restrict__ Jn,
+                                                          double* __restrict__ xT, const double* __restrict__ xT2,
+                                                          double* __restrict__ uT, const double* __restrict__ uT2,
+                                                          int* __restrict__ converged, int* __restrict__ active,
+                                                          const double tol, const long xrow, const long urow) {
+    const long slot = blockIdx.x;
+    if (slot >= count) return;
+    const long t = list[slot];
+    for (long e = threadIdx.x; e < xrow; e += blockDim.x) xT[t * xrow + e] = xT2[t * xrow + e];
+    for (long e = threadIdx.x; e < urow; e += blockDim.x) uT[t * urow + e] = uT2[t * urow + e];
+    if (threadIdx.x == 0) {
+        const double jn = Jn[t];
+        const int cv = (__builtin_fabs(J[t] - jn) <= tol) ? 1 : 0;   // NaN compares false: never "converged"
+        J[t] = jn;
+        converged[t] = cv;
+        active[t] = cv ? 0 : 1;
+    }
+}
+}  // namespace zm
+
+extern "C" int zm_ilqr_accept_f64(const int32_t* list, int64_t count, double* J, const double* Jn, double* xTraj,
+                                  const double* xTrajNew, double* uTraj, const double* uTrajNew, int32_t* converged,
+                                  int32_t* active, double tol, int64_t batch, int T, int n, int m, void* stream) {
+    if (batch == 0 || count == 0) return ZM_OK;
+    if (!list || !J || !Jn || !xTraj || !xTrajNew || !uTraj || !uTrajNew || !converged || !active)
+        return zm::set_error(ZM_EINVAL, "zm_ilqr_accept_f64: null pointer");
+    if (count < 0 || count > batch || T < 1 || n < 1 || m < 1) return zm::set_error(ZM_EINVAL, "zm_ilqr_accept_f64: bad size");
+    hipLaunchKernelGGL(zm::ilqr_accept_kernel, dim3((unsigned)count), dim3(256), 0, (hipStream_t)stream, (const int*)list,
+                       (long)count, J, Jn, xTraj, xTrajNew, uTraj, uTrajNew, (int*)converged, (int*)active, tol,
+                       (long)(T + 1) * n, (long)T * m);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}

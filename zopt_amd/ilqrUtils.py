@@ -402,7 +402,7 @@ def _ilqr_or_ddp(dynamics, runningCost, terminalCost, x0, uGuess, maxIter, tol, 
         f_xx = torch.empty((B, N, n, n, n), dtype=dt, device=dev)
         f_ux = torch.empty((B, N, n, m, n), dtype=dt, device=dev)
         f_uu = torch.empty((B, N, n, m, m), dtype=dt, device=dev)
-    converged = torch.zeros(B, dtype=torch.bool, device=dev)
+    converged = torch.zeros(B, dtype=torch.int32, device=dev)
     active = torch.ones(B, dtype=torch.int32, device=dev)
     it = 0
     while it < maxIter and bool(active.any()):                                                        # (:301-303)
@@ -432,12 +432,10 @@ def _ilqr_or_ddp(dynamics, runningCost, terminalCost, x0, uGuess, maxIter, tol, 
                                                       uT.data_ptr(), alphas.data_ptr(), 16, ids.data_ptr(), int(ids.numel()),
                                                       xT2.data_ptr(), uT2.data_ptr(), Jn.data_ptr(), None, B, N, st),
                    "iterativeLqr: forward pass")
-        act = active.bool()
-        converged = torch.where(act, (J - Jn).abs() <= tol, converged)                               # (:318)
-        J = torch.where(act, Jn, J)
-        xT = torch.where(act[:, None, None], xT2, xT)
-        uT = torch.where(act[:, None, None], uT2, uT)
-        active = (~converged).to(torch.int32)
+        # accept: converged = |J - J_new| <= tol, (traj, J) <- (traj_new, J_new) on the listed rows only             (:316-320)
+        _lib.check(lib.zm_ilqr_accept_f64(ids.data_ptr(), int(ids.numel()), J.data_ptr(), Jn.data_ptr(), xT.data_ptr(),
+                                          xT2.data_ptr(), uT.data_ptr(), uT2.data_ptr(), converged.data_ptr(),
+                                          active.data_ptr(), float(tol), B, N, n, m, st), "iterativeLqr: accept")
         it += 1
     tmpl = uGuess
     fp32_in = (arr.is_torch(tmpl) and tmpl.dtype == torch.float32) or \
@@ -446,7 +444,7 @@ def _ilqr_or_ddp(dynamics, runningCost, terminalCost, x0, uGuess, maxIter, tol, 
     if fp32_in:
         outs = [o.to(torch.float32) for o in outs]
     xo, uo, Lo, Jo = (arr.result_like(o, tmpl) for o in outs)
-    co = arr.result_like(converged.reshape(lead), tmpl)
+    co = arr.result_like(converged.bool().reshape(lead), tmpl)
     if not arr.is_torch(tmpl) and len(lead) == 0:
         Jo, co = float(Jo), bool(co)
     return Trajectory(xo, uo), Lo, Jo, co
