@@ -135,11 +135,8 @@ int lqr_backward_lds_dispatch(const double* A, const double* B, const double* Q,
                               int T, int n, int m, hipStream_t st) {
     const size_t doubles = 3 * (size_t)n * n + 3 * (size_t)n * m + (size_t)m * (n + m) + (size_t)m * m;
     const size_t bytes = doubles * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        ZM_HIP_CHECK(hipFuncSetAttribute((const void*)lqr_backward_lds_f64, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-        attr_set = true;
-    }
+    // per launch (cheap): the attribute is per device, and several devices may be driven from one process
+    ZM_HIP_CHECK(hipFuncSetAttribute((const void*)lqr_backward_lds_f64, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     hipLaunchKernelGGL(lqr_backward_lds_f64, dim3((unsigned)batch), dim3(256), bytes, st, A, B, Q, R, L, (long)batch, T, n, m);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;

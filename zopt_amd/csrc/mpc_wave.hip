@@ -343,12 +343,9 @@ template <int NS, int MC>
 static int launch_wave(const MpcTabs& t, const MpcArgs& g, hipStream_t st) {
     const size_t bytes = (size_t)4 * g.N * WS_STAGE * sizeof(double);
     if (bytes > 150 * 1024) return ZM_EUNSUPPORTED;   // horizon too long for LDS: the lane-per-instance kernel takes it
-    static bool attr_set = false;
-    if (!attr_set) {
-        ZM_HIP_CHECK(hipFuncSetAttribute((const void*)mpc_solve_wave_kernel<NS, MC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         150 * 1024));
-        attr_set = true;
-    }
+    // per launch (cheap): the attribute is per device, and several devices may be driven from one process
+    ZM_HIP_CHECK(hipFuncSetAttribute((const void*)mpc_solve_wave_kernel<NS, MC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     150 * 1024));
     hipLaunchKernelGGL((mpc_solve_wave_kernel<NS, MC>), dim3((unsigned)((g.batch + 3) / 4)), dim3(64), bytes, st, t.A, t.B, t.K,
                        t.Minv, t.x_lb, t.x_ub, t.u_lb, t.u_ub, g);
     ZM_HIP_CHECK(hipGetLastError());
