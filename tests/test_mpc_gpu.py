@@ -269,3 +269,26 @@ def test_bad_arguments(mpc):
         prob.solve(one, solver="CLARABEL")
     with pytest.raises(ValueError):
         mpc.lqrMpc(np.eye(16), np.ones((16, 5)), np.eye(16), np.eye(5), 2, -np.ones(16), np.ones(16), -np.ones(5), np.ones(5)).solve(np.ones(16))
+
+
+@pytest.mark.parametrize("n,m", [(3, 2), (5, 3), (6, 1), (9, 4), (10, 2), (3, 3)])
+def test_shapes_between_the_compiled_kernels(mpc, n, m):
+    """Any n <= 12, m <= 4: shapes without a kernel of their own are embedded in the next compiled one (inert padding);
+    answers are checked against the condensed-QP reference solve and the KKT conditions."""
+    rng = np.random.default_rng(100 + 10 * n + m)
+    N = 8
+    A, B, Q, R, Qf = _random_problem(rng, n, m, N)
+    x_ub, u_ub = np.full(n, 3.0), np.full(m, 0.4)
+    prob = mpc.lqrMpc(A, B, Q, R, N, -x_ub, x_ub, -u_ub, u_ub, Qf=Qf)
+    x0 = 0.5 * rng.standard_normal((5, n))
+    u0, traj, status = prob.solve(x0, eps_abs=1e-7, eps_rel=1e-7, max_iter=100000)
+    assert u0.shape == (5, m) and traj.xTraj.shape == (5, N + 1, n) and traj.uTraj.shape == (5, N, m)
+    for b in range(5):
+        if status[b] != "optimal":
+            continue
+        kkt = mo.kkt_residuals(A, B, Q, R, Qf, N, -x_ub, x_ub, -u_ub, u_ub, x0[b], traj.xTraj[b], traj.uTraj[b], act_tol=1e-5)
+        assert kkt["dyn"] <= 1e-12 and kkt["bound"] <= 1e-5 and kkt["stat"] <= 1e-4
+    assert np.sum(status == "optimal") >= 3
+    b = int(np.where(status == "optimal")[0][0])
+    xr, ur, fr = mo.solve_reference(A, B, Q, R, Qf, N, -x_ub, x_ub, -u_ub, u_ub, x0[b])
+    assert np.max(np.abs(traj.uTraj[b] - ur)) <= 2e-4

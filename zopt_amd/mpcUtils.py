@@ -55,6 +55,30 @@ class lqrMpc():
         # one penalty for every instance: the geometric mean of the cost curvatures keeps both blocks of the
         # w-update Hessian (2Q + rho I, 2R + rho I) comparably conditioned
         self.rho = float(np.sqrt(max(np.trace(2 * self.Q) / self.n, 1e-12) * max(np.trace(2 * self.R) / self.m, 1e-12)))
+        # The solve kernels are compiled for a few (n, m); any other n <= 12, m <= 4 is embedded in the next one: the extra
+        # states follow x+ = 0 from x = 0 with unit weight and no bound, the extra controls act on nothing and cost u^2 --
+        # they stay exactly zero and are sliced off the results.
+        self._n_user, self._m_user = self.n, self.m
+        fit = [(ns, mc) for (ns, mc) in self._COMPILED if ns >= self.n and mc >= self.m]
+        if not fit:
+            raise ValueError(f"lqrMpc: (n={self.n}, m={self.m}) outside the compiled kernels (n <= 12, m <= 4)")
+        ns, mc = min(fit, key=lambda t: (t[0] * t[1], t[0]))
+        if (ns, mc) != (self.n, self.m):
+            n0, m0 = self.n, self.m
+            pad2 = lambda X, r, c, d: np.block([[X, np.zeros((X.shape[0], c - X.shape[1]))],
+                                                [np.zeros((r - X.shape[0], X.shape[1])), d * np.eye(r - X.shape[0], c - X.shape[1])]])
+            self.A = pad2(self.A, ns, ns, 0.0)
+            self.B = pad2(self.B, ns, mc, 0.0)
+            self.Q, self.Qf = pad2(self.Q, ns, ns, 1.0), pad2(self.Qf, ns, ns, 1.0)
+            self.R = pad2(self.R, mc, mc, 1.0)
+            inf = np.inf
+            self.x_lb = np.concatenate([self.x_lb, np.full(ns - n0, -inf)])
+            self.x_ub = np.concatenate([self.x_ub, np.full(ns - n0, inf)])
+            self.u_lb = np.concatenate([self.u_lb, np.full(mc - m0, -inf)])
+            self.u_ub = np.concatenate([self.u_ub, np.full(mc - m0, inf)])
+            self.n, self.m = ns, mc
+
+    _COMPILED = ((12, 4), (8, 4), (4, 2), (4, 1), (2, 2), (2, 1), (1, 1))
 
     N_LEVELS, RHO_STEP = 7, 5.0      # adaptive penalty: rho * 5^(l - 3), l = 0..6  (OSQP changes rho only by factors >= 5)
 
@@ -118,11 +142,14 @@ class lqrMpc():
         if kwargs:
             raise TypeError(f"unknown solver options {sorted(kwargs)}")
         shp = tuple(x0.shape) if hasattr(x0, "shape") else tuple(np.shape(x0))
-        if len(shp) < 1 or shp[-1] != self.n:
-            raise ValueError(f"x0 has shape {shp}, expected (..., {self.n})")
+        if len(shp) < 1 or shp[-1] != self._n_user:
+            raise ValueError(f"x0 has shape {shp}, expected (..., {self._n_user})")
         lead = shp[:-1]
         d, (K, Mi, n_levels, level0) = self._device_problem(rho, adaptive)
-        dx0 = arr.to_device(x0, torch.float64).reshape(-1, self.n).contiguous()
+        dx0 = arr.to_device(x0, torch.float64).reshape(-1, self._n_user)
+        if self.n != self._n_user:
+            dx0 = torch.nn.functional.pad(dx0, (0, self.n - self._n_user))
+        dx0 = dx0.contiguous()
         Bn = dx0.shape[0]
         dev = dx0.device
         N, n, m = self.N, self.n, self.m
@@ -146,8 +173,8 @@ class lqrMpc():
         self.last_iterations = its.reshape(lead).cpu().numpy()
         self.last_residuals = res.reshape(lead + (2,)).cpu().numpy()
         codes = st.cpu().numpy().reshape(lead)
-        xo = arr.result_like(xT.reshape(lead + (N + 1, n)), x0)
-        uo = arr.result_like(uT.reshape(lead + (N, m)), x0)
+        xo = arr.result_like(xT.reshape(lead + (N + 1, n))[..., :self._n_user], x0)
+        uo = arr.result_like(uT.reshape(lead + (N, m))[..., :self._m_user], x0)
         if len(lead) == 0:
             status = _STATUS[int(codes)]
         else:
