@@ -19,23 +19,26 @@ def main():
     ap.add_argument("--n", type=int, default=64)
     ap.add_argument("--m", type=int, default=16)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--fp64", action="store_true", help="time the fp64 LDS coverage kernel (zm_lqr_backward_f64) at the same shape")
     args = ap.parse_args()
     import torch
     from zopt_amd import _lib
     b, T, n, m = args.batch, args.T, args.n, args.m
     g = torch.Generator(device="cuda").manual_seed(3)
-    rn = lambda *s: torch.randn(*s, device="cuda", dtype=torch.float32, generator=g)
+    dt = torch.float64 if args.fp64 else torch.float32
+    rn = lambda *s: torch.randn(*s, device="cuda", dtype=dt, generator=g)
     A1 = rn(b, n, n) * (0.9 / n ** 0.5)
     B1 = rn(b, n, m)
     M, N = rn(b, n, n), rn(b, m, m)
-    Q1 = M @ M.transpose(-1, -2) / n + torch.eye(n, device="cuda")
-    R1 = N @ N.transpose(-1, -2) / m + torch.eye(m, device="cuda")
+    Q1 = M @ M.transpose(-1, -2) / n + torch.eye(n, device="cuda", dtype=dt)
+    R1 = N @ N.transpose(-1, -2) / m + torch.eye(m, device="cuda", dtype=dt)
     A, B, Q, R = (X[:, None].expand(b, T, *X.shape[1:]).contiguous() for X in (A1, B1, Q1, R1))
     del M, N
-    L = torch.empty((b, T, m, n), device="cuda", dtype=torch.float32)
+    L = torch.empty((b, T, m, n), device="cuda", dtype=dt)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     lib = _lib.lib()
-    call = lambda: _lib.check(lib.zm_lqr_backward_f32(A.data_ptr(), B.data_ptr(), Q.data_ptr(), R.data_ptr(), L.data_ptr(),
+    fn = lib.zm_lqr_backward_f64 if args.fp64 else lib.zm_lqr_backward_f32
+    call = lambda: _lib.check(fn(A.data_ptr(), B.data_ptr(), Q.data_ptr(), R.data_ptr(), L.data_ptr(),
                                                       b, T, n, m, st), "bench")
     call()
     torch.cuda.synchronize()
@@ -50,8 +53,8 @@ def main():
     steps = b * T
     nt = (n + 15) // 16
     mfma = 4 * nt * nt + 4 * nt * (nt + 1) + 4 * nt ** 3 + 4 * nt * nt + 4 * nt + 4 * nt * nt + 4 * nt * nt + 4 * nt ** 3
-    bytes_step = 4 * (2 * n * n + 2 * n * m + m * m)
-    print(json.dumps({"workload": f"discreteFiniteHorizonLqr n={n} m={m} T={T} batch={b} fp32", "ms": best * 1e3,
+    bytes_step = (8 if args.fp64 else 4) * (2 * n * n + 2 * n * m + m * m)
+    print(json.dumps({"workload": f"discreteFiniteHorizonLqr n={n} m={m} T={T} batch={b} {'fp64 (LDS coverage kernel)' if args.fp64 else 'fp32'}", "ms": best * 1e3,
                       "horizon_steps_per_s": steps / best, "algorithmic_GBps": steps * bytes_step / best / 1e9,
                       "mfma_TFLOPs": steps * mfma * 2048 / best / 1e12, "finite": bool(torch.isfinite(L).all().item())}))
 

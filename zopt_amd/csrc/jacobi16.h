@@ -76,30 +76,49 @@ __device__ __forceinline__ void psd_project_lds(double* As, double* Vs, double* 
         // triangles are transformed identically afterwards
     }
     wave_lds_sync();
-    const bool pair_on = pr < (K >> 1);
+    // Round-robin schedule of K players (player K-1 stays, the others rotate), tabulated once per call: entry (r, pair) =
+    // p | q << 8 | active << 16 with p < q.  (Measured: the routine is bound by LDS bandwidth -- 27 b64 accesses per lane and
+    // round through the one LDS pipe of the CU -- not by these integer instructions or by latency.)
+    __shared__ int jtab[(PK - 1) * (PK / 2)];
+    for (int e = lane; e < (K - 1) * (PK / 2); e += 64) {
+        const int r = e >> 3, pp = e & 7;
+        int p, q;
+        if (pp == 0) {
+            p = K - 1;
+            q = r;
+        } else {
+            p = r + pp;
+            p = p >= K - 1 ? p - (K - 1) : p;
+            q = r - pp + (K - 1);
+            q = q >= K - 1 ? q - (K - 1) : q;
+        }
+        if (p > q) {
+            const int t = p;
+            p = q;
+            q = t;
+        }
+        const bool on = (pp < (K >> 1)) && (q < k);   // q == k: bye
+        jtab[e] = on ? (p | (q << 8) | (1 << 16)) : 0;
+    }
+    wave_lds_sync();
     for (int sweep = 0; sweep < 20; ++sweep) {
         bool rotated = false, big = false;
         for (int r = 0; r < K - 1; ++r) {
-            // round-robin pairing of K players: player K-1 stays, the others rotate (no modulo: one conditional subtract)
-            int p, q;
-            if (pr == 0) {
-                p = K - 1;
-                q = r;
-            } else {
-                p = r + pr;
-                p = p >= K - 1 ? p - (K - 1) : p;
-                q = r - pr + (K - 1);
-                q = q >= K - 1 ? q - (K - 1) : q;
-            }
-            if (p > q) {
-                const int t = p;
-                p = q;
-                q = t;
-            }
-            const bool on = pair_on && q < k;   // q == k: bye
-            p = on ? p : 0;
-            q = on ? q : 0;
+            const int ent = jtab[(r << 3) + pr];
+            const int p = ent & 0xff, q = (ent >> 8) & 0xff;
+            const bool on = (ent >> 16) != 0;
             const double app = As[p * PLD + p], aqq = As[q * PLD + q], apq = As[p * PLD + q];
+            // the column data the rotation will be applied to does not depend on the angle: fetch it now, so that its LDS
+            // latency runs under the rotation's arithmetic instead of after it
+            double ca[2][4];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int i = sub + 8 * h2;
+                ca[h2][0] = As[i * PLD + p];
+                ca[h2][1] = As[i * PLD + q];
+                ca[h2][2] = Vs[i * PLD + p];
+                ca[h2][3] = Vs[i * PLD + q];
+            }
             const double apq2 = apq * apq, dd = __builtin_fabs(app * aqq);
             const bool rot = on && (apq2 > 0x1p-104 * dd);
             // quadratic convergence: if every rotation of this sweep started from |a_pq| <= 2^-26 sqrt|a_pp a_qq|, the sweep
@@ -107,11 +126,17 @@ __device__ __forceinline__ void psd_project_lds(double* As, double* Vs, double* 
             big |= (__ballot(on && (apq2 > 0x1p-52 * dd)) != 0ull);
             double c = 1.0, s = 0.0;
             if (rot) {
-                // t = sgn(d) 2 a_pq / (|d| + sqrt(d^2 + 4 a_pq^2)),  d = a_qq - a_pp   (the smaller root of t^2 + 2 tau t - 1)
+                // t = sgn(d) 2 a_pq / (|d| + sqrt(d^2 + 4 a_pq^2)),  d = a_qq - a_pp   (the smaller root of t^2 + 2 tau t - 1).
+                // The angle only steers convergence, so t takes one Newton step per reciprocal (~1e-9); orthogonality needs
+                // c^2 + s^2 = 1 to rounding, so c = 1/sqrt(1 + t^2) takes two.
                 const double d = aqq - app, b2 = 2.0 * apq;
                 const double x = __builtin_fma(d, d, b2 * b2);
-                const double h = x * jac_rsqrt(x);
-                const double t = (d >= 0.0 ? b2 : -b2) * jac_rcp(__builtin_fabs(d) + h);
+                double y = __builtin_amdgcn_rsq(x);
+                y = y * __builtin_fma(-0.5 * x, y * y, 1.5);
+                const double den = __builtin_fabs(d) + x * y;
+                double rc = __builtin_amdgcn_rcp(den);
+                rc = __builtin_fma(rc, __builtin_fma(-den, rc, 1.0), rc);
+                const double t = (d >= 0.0 ? b2 : -b2) * rc;
                 c = jac_rsqrt(__builtin_fma(t, t, 1.0));
                 s = t * c;
             }
@@ -121,12 +146,10 @@ __device__ __forceinline__ void psd_project_lds(double* As, double* Vs, double* 
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
                     const int i = sub + 8 * h2;
-                    const double ap = As[i * PLD + p], aq = As[i * PLD + q];
-                    const double vp = Vs[i * PLD + p], vq = Vs[i * PLD + q];
-                    As[i * PLD + p] = c * ap - s * aq;
-                    As[i * PLD + q] = s * ap + c * aq;
-                    Vs[i * PLD + p] = c * vp - s * vq;
-                    Vs[i * PLD + q] = s * vp + c * vq;
+                    As[i * PLD + p] = c * ca[h2][0] - s * ca[h2][1];
+                    As[i * PLD + q] = s * ca[h2][0] + c * ca[h2][1];
+                    Vs[i * PLD + p] = c * ca[h2][2] - s * ca[h2][3];
+                    Vs[i * PLD + q] = s * ca[h2][2] + c * ca[h2][3];
                 }
             }
             wave_lds_sync();
