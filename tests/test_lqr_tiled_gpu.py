@@ -120,9 +120,9 @@ def test_unsupported_shapes_raise(lqr):
 
 
 @pytest.mark.parametrize("n,m,T,batch", [(64, 16, 6, 3), (20, 4, 9, 2), (13, 1, 5, 2), (12, 5, 7, 3), (33, 7, 4, 2), (3, 16, 3, 2),
-                                         (48, 12, 30, 2)])
+                                         (48, 12, 30, 2), (16, 16, 8, 3), (32, 16, 12, 2), (48, 16, 5, 2), (49, 3, 4, 2)])
 def test_fp64_beyond_tile16_lds_kernel(lqr, n, m, T, batch):
-    """fp64 inputs outside n <= 12, m <= 4 run the LDS coverage kernel (same formulas, reference operation order): 1e-10."""
+    """fp64 inputs outside n <= 12, m <= 4 run the fp64 MFMA tile kernel (n <= 48) or the LDS coverage kernel (beyond): 1e-10."""
     A, B, Q, R = problems.random_time_varying(batch, T, n, m, seed=50 + n + m, dtype=np.float64)
     Lg = lqr.discreteFiniteHorizonLqr(A, B, Q, R, T)
     Lr = zo.discreteFiniteHorizonLqr(A, B, Q, R, T)
@@ -140,3 +140,17 @@ def test_fp64_lds_kernel_pivoting_and_nonsymmetric(lqr):
     Lg = lqr.discreteFiniteHorizonLqr(A, B, Q, R, T)
     Lr = zo.discreteFiniteHorizonLqr(A, B, Q, R, T)
     assert np.max(np.abs(Lg - Lr)) <= 1e-10 * np.max(np.abs(Lr))
+
+
+def test_fp64_tile_kernel_and_lds_kernel_agree(lqr, monkeypatch):
+    """The two fp64 paths for medium sizes (MFMA tiles / LDS coverage kernel, ZOPT_AMD_LQR_PATH=lds) give the same gains."""
+    import subprocess, sys, json, os
+    A, B, Q, R = problems.random_time_varying(2, 6, 24, 8, seed=77)
+    La = lqr.discreteFiniteHorizonLqr(A, B, Q, R, 6)
+    code = ("import numpy as np, json, sys; sys.path.insert(0, %r); from tests import problems; from zopt_amd import lqrUtils;"
+            "A,B,Q,R = problems.random_time_varying(2, 6, 24, 8, seed=77); print(json.dumps(lqrUtils.discreteFiniteHorizonLqr(A,B,Q,R,6).tolist()))"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZOPT_AMD_LQR_PATH="lds"), capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-500:]
+    Lb = np.array(json.loads(out.stdout.strip().splitlines()[-1]))
+    assert np.max(np.abs(La - Lb)) <= 1e-11 * np.max(np.abs(Lb))

@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--n", type=int, default=64)
     ap.add_argument("--m", type=int, default=16)
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--fp64", action="store_true", help="time the fp64 LDS coverage kernel (zm_lqr_backward_f64) at the same shape")
+    ap.add_argument("--fp64", action="store_true", help="time zm_lqr_backward_f64 (fp64 MFMA tile kernel up to n=48, LDS coverage kernel beyond) at the same shape")
     args = ap.parse_args()
     import torch
     from zopt_amd import _lib
@@ -54,7 +54,7 @@ def main():
     nt = (n + 15) // 16
     mfma = 4 * nt * nt + 4 * nt * (nt + 1) + 4 * nt ** 3 + 4 * nt * nt + 4 * nt + 4 * nt * nt + 4 * nt * nt + 4 * nt ** 3
     bytes_step = (8 if args.fp64 else 4) * (2 * n * n + 2 * n * m + m * m)
-    print(json.dumps({"workload": f"discreteFiniteHorizonLqr n={n} m={m} T={T} batch={b} {'fp64 (LDS coverage kernel)' if args.fp64 else 'fp32'}", "ms": best * 1e3,
+    print(json.dumps({"workload": f"discreteFiniteHorizonLqr n={n} m={m} T={T} batch={b} {'fp64 (MFMA tiles up to n=48, LDS coverage kernel beyond)' if args.fp64 else 'fp32'}", "ms": best * 1e3,
                       "horizon_steps_per_s": steps / best, "algorithmic_GBps": steps * bytes_step / best / 1e9,
                       "mfma_TFLOPs": steps * mfma * 2048 / best / 1e12, "finite": bool(torch.isfinite(L).all().item())}))
 

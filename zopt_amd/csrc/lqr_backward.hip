@@ -294,6 +294,8 @@ int lqr_backward_dma_dispatch(const double* A, const double* B, const double* Q,
 namespace zm {
 int lqr_backward_lds_dispatch(const double* A, const double* B, const double* Q, const double* R, double* L, int64_t batch,
                               int T, int n, int m, hipStream_t st);   // lqr_backward_lds_f64.hip
+int lqr_backward_tiled_f64_dispatch(const double* A, const double* B, const double* Q, const double* R, double* L, int64_t batch,
+                                    int T, int n, int m, hipStream_t st);   // lqr_backward_tiled_f64.hip (n <= 48)
 }
 
 extern "C" int zm_lqr_backward_supported(int n, int m, int elem_size) {
@@ -314,7 +316,18 @@ extern "C" int zm_lqr_backward_f64(const double* A, const double* B, const doubl
         return zm::set_error(ZM_EUNSUPPORTED, "zm_lqr_backward_f64: T*n*n or batch too large");
     if (batch == 0) return ZM_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (n > 12 || m > 4) return zm::lqr_backward_lds_dispatch(A, B, Q, R, L, batch, T, n, m, st);   // coverage kernel
+    if (n > 12 || m > 4) {
+        // medium sizes: fp64 MFMA tile kernel (n <= 48); beyond, or with ZOPT_AMD_LQR_PATH=lds: the LDS coverage kernel
+        static const bool force_lds = [] {
+            const char* e = getenv("ZOPT_AMD_LQR_PATH");
+            return e && e[0] == 'l';
+        }();
+        if (!force_lds) {
+            const int rc = zm::lqr_backward_tiled_f64_dispatch(A, B, Q, R, L, batch, T, n, m, st);
+            if (rc != ZM_EUNSUPPORTED) return rc;
+        }
+        return zm::lqr_backward_lds_dispatch(A, B, Q, R, L, batch, T, n, m, st);
+    }
     // ZOPT_AMD_LQR_PATH=reg forces the register-prefetch kernel (A/B measurements); default: LDS-DMA when eligible.
     static const bool force_reg = [] {
         const char* e = getenv("ZOPT_AMD_LQR_PATH");
