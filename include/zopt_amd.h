@@ -102,7 +102,8 @@ int zm_ilqr_backward_f64(const double* f_x, const double* f_u, const double* c_x
 /* ---- registered device models (the reference differentiates / rolls out arbitrary Python callables with JAX;
  *      a kernel needs the model in device code) ------------------------------------------------------------------ */
 #define ZM_MODEL_LINEAR 1     /* x+ = A x + B u, A (n,n), B (n,m) device pointers shared by the whole batch           */
-#define ZM_MODEL_QUADCOPTER 2 /* x+ = x + dt * Quadcopter.inertialDynamics(x,u)  (zopt/quadcopter.py:116-144), n=12, m=4 */
+#define ZM_MODEL_QUADCOPTER 2 /* x+ = x + dt * Quadcopter.inertialDynamics(x,u)  (zopt/quadcopter.py:116-144), n=12, m=4; dt = 0: the derivative */
+#define ZM_MODEL_QUADCOPTER_RB 3 /* same with Quadcopter.rigidBodyDynamics (:70-113), n=8, m=4; wind_ned holds the BODY-frame wind */
 typedef struct zm_model_t {
     int kind, n, m, reserved;
     double dt;              /* quadcopter: Euler step (demos/iterativeLqr.py:23,35) */
@@ -211,6 +212,15 @@ int zm_riccati_value_f64(const double* f_x, const double* f_u, const double* f_x
  */
 int zm_quadratic_dynamics_f64(const zm_model_t* model, const double* xTraj, const double* uTraj, const int32_t* active,
                               double* f_xx, double* f_ux, double* f_uu, int64_t batch, int T, void* stream);
+
+/* Batched trim of the quadcopter (the producer side of the path).
+ * Replaces: zopt/quadcopter.py:146-177 Quadcopter.trim(uvwTrim): find x = [uvw, p,q,r,phi,theta], u = [thrust,mx,my,mz] with
+ *           rigidBodyDynamics(x, u) = 0 (the reference minimises the squared residual with SciPy BFGS; its test accepts
+ *           |residual| <= 1e-3).  Levenberg-Marquardt from the reference's start point, one lane per instance.
+ * in : uvw (batch,3) [device]; wind_body (3) HOST pointer or NULL (body-frame wind, zeros in the reference's trim)
+ * out: xTrim (batch,8)  uTrim (batch,4)  resid (batch) = |rigidBodyDynamics|_2 or NULL  ok (batch) int32 (resid <= tol) or NULL */
+int zm_quadcopter_trim_f64(const double* uvw, const double* wind_body, double* xTrim, double* uTrim, double* resid, int32_t* ok,
+                           int64_t batch, double tol, void* stream);
 
 /* Batched projection onto the positive definite cone: A <- V max(w, eps) V^T with (w, V) = eigh((A + A^T)/2).
  * Replaces: zopt/ilqrUtils.py:217-219 ensurePositiveDefinite (jnp.linalg.eigh symmetrises its input) and its users

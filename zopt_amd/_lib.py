@@ -53,6 +53,7 @@ SYMBOLS = {
     # (A, B, Q, R, Qf, rho, N, n, m, K, Minv, stream)
     "zm_condition_dynamics_f64": (ctypes.c_int, [_c_dp] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                                               ctypes.c_void_p]),
+    "zm_quadcopter_trim_f64": (ctypes.c_int, [_c_dp] * 6 + [ctypes.c_int64, ctypes.c_double, ctypes.c_void_p]),
     "zm_mpc_setup_f64": (ctypes.c_int, [_c_dp] * 5 + [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_dp, _c_dp,
                                                     ctypes.c_void_p]),
     # (A, B, K, Minv, x_lb, x_ub, u_lb, u_ub, x0, rho, eps_abs, eps_rel, max_iter, ws, xTraj, uTraj, status, iters, resid,

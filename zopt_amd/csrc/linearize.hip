@@ -184,6 +184,9 @@ static int zm_check_model(const zm_model_t* model, zm_model_t& md, const char* w
     if (md.kind == ZM_MODEL_QUADCOPTER) {
         md.n = 12;
         md.m = 4;
+    } else if (md.kind == ZM_MODEL_QUADCOPTER_RB) {
+        md.n = 8;
+        md.m = 4;
     } else if (md.kind == ZM_MODEL_LINEAR) {
         if (!md.A || !md.B) return zm::set_error(ZM_EINVAL, "%s: linear model needs A, B", who);
     } else {
@@ -245,6 +248,145 @@ extern "C" int zm_quadratic_dynamics_f64(const zm_model_t* model, const double* 
     if (batch == 0) return ZM_OK;
     hipLaunchKernelGGL(zm::quadratic_dynamics_kernel, dim3((unsigned)(batch * T)), dim3(64), 0, (hipStream_t)stream, md, xTraj,
                        uTraj, (const int*)active, f_xx, f_ux, f_uu, (long)batch, T);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Batched trim of the quadcopter: for given body velocities uvw find (p, q, r, phi, theta) and (thrust, mx, my, mz) with
+// rigidBodyDynamics(x, u) = 0.  Replaces zopt/quadcopter.py:146-177 Quadcopter.trim, which minimises the squared residual with
+// SciPy BFGS from z0 = (0,0,0,0,0, g,0,0,0); the reference's test accepts any point with |residual| <= 1e-3
+// (tests/test_quadcopter.py:89-99).  Here: Levenberg-Marquardt on the 8 residuals from the same z0, Jacobian by dual numbers,
+// one lane per instance (8 equations, 9 unknowns: the damping selects the small-step solution).
+namespace zm {
+
+__global__ __launch_bounds__(64) void quad_trim_kernel(const double* __restrict__ uvw, const double wb0, const double wb1,
+                                                       const double wb2, double* __restrict__ xTrim,
+                                                       double* __restrict__ uTrim, double* __restrict__ resid,
+                                                       int* __restrict__ ok, const long batch, const double tol) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch) return;
+    const double v0 = uvw[i * 3], v1 = uvw[i * 3 + 1], v2 = uvw[i * 3 + 2];
+    double z[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 9.807, 0.0, 0.0, 0.0};
+    auto residual = [&](const double (&zz)[9], double (&r)[8]) {
+        const double x8[8] = {v0, v1, v2, zz[0], zz[1], zz[2], zz[3], zz[4]};
+        const double u4[4] = {zz[5], zz[6], zz[7], zz[8]};
+        const double wb[3] = {wb0, wb1, wb2};
+        quad_rigid_body<double>(x8, u4, wb, r);
+    };
+    double r[8];
+    residual(z, r);
+    double cost = 0.0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cost += r[e] * r[e];
+    double lam = 1e-3;
+    for (int it = 0; it < 200 && cost > tol * tol * 1e-6; ++it) {
+        // Jacobian column by column on dual numbers; normal equations A = J^T J, b = J^T r
+        double J[8][9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            Dual x8[8] = {{v0, 0}, {v1, 0}, {v2, 0}, {z[0], 0}, {z[1], 0}, {z[2], 0}, {z[3], 0}, {z[4], 0}};
+            Dual u4[4] = {{z[5], 0}, {z[6], 0}, {z[7], 0}, {z[8], 0}};
+            if (j < 5) x8[3 + j].d = 1.0; else u4[j - 5].d = 1.0;
+            const Dual wb[3] = {{wb0, 0}, {wb1, 0}, {wb2, 0}};
+            Dual rd[8];
+            quad_rigid_body<Dual>(x8, u4, wb, rd);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) J[e][j] = rd[e].d;
+        }
+        double A[9][9], b[9];
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            double s = 0.0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += J[e][p] * r[e];
+            b[p] = s;
+#pragma unroll
+            for (int q = 0; q <= p; ++q) {
+                double t = 0.0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t += J[e][p] * J[e][q];
+                A[p][q] = t;
+                A[q][p] = t;
+            }
+        }
+        bool accepted = false;
+        for (int tr = 0; tr < 12 && !accepted; ++tr) {
+            // Cholesky of A + lam (diag(A) + 1e-9 I), solve for the step
+            double Lc[9][9], y[9], d[9];
+            bool pd = true;
+#pragma unroll
+            for (int p = 0; p < 9; ++p) {
+#pragma unroll
+                for (int q = 0; q <= p; ++q) {
+                    double s = A[p][q] + ((p == q) ? lam * (A[p][p] + 1e-9) : 0.0);
+#pragma unroll
+                    for (int k = 0; k < q; ++k) s -= Lc[p][k] * Lc[q][k];
+                    if (p == q) {
+                        pd = pd && (s > 0.0);
+                        Lc[p][p] = sqrt(s > 0.0 ? s : 1.0);
+                    } else {
+                        Lc[p][q] = s / Lc[q][q];
+                    }
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 9; ++p) {
+                double s = -b[p];
+#pragma unroll
+                for (int k = 0; k < p; ++k) s -= Lc[p][k] * y[k];
+                y[p] = s / Lc[p][p];
+            }
+#pragma unroll
+            for (int p = 8; p >= 0; --p) {
+                double s = y[p];
+#pragma unroll
+                for (int k = p + 1; k < 9; ++k) s -= Lc[k][p] * d[k];
+                d[p] = s / Lc[p][p];
+            }
+            double zn[9], rn[8];
+#pragma unroll
+            for (int p = 0; p < 9; ++p) zn[p] = z[p] + d[p];
+            residual(zn, rn);
+            double cn = 0.0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cn += rn[e] * rn[e];
+            if (pd && cn < cost) {
+#pragma unroll
+                for (int p = 0; p < 9; ++p) z[p] = zn[p];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] = rn[e];
+                cost = cn;
+                lam = lam > 1e-10 ? lam * 0.1 : lam;
+                accepted = true;
+            } else {
+                lam *= 10.0;
+            }
+        }
+        if (!accepted) break;
+    }
+    xTrim[i * 8 + 0] = v0;
+    xTrim[i * 8 + 1] = v1;
+    xTrim[i * 8 + 2] = v2;
+#pragma unroll
+    for (int p = 0; p < 5; ++p) xTrim[i * 8 + 3 + p] = z[p];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) uTrim[i * 4 + p] = z[5 + p];
+    const double rn = sqrt(cost);
+    if (resid) resid[i] = rn;
+    if (ok) ok[i] = (rn <= tol) ? 1 : 0;
+}
+
+}  // namespace zm
+
+extern "C" int zm_quadcopter_trim_f64(const double* uvw, const double* wind_body, double* xTrim, double* uTrim, double* resid,
+                                      int32_t* ok, int64_t batch, double tol, void* stream) {
+    if (batch == 0) return ZM_OK;
+    if (!uvw || !xTrim || !uTrim) return zm::set_error(ZM_EINVAL, "zm_quadcopter_trim_f64: null pointer");
+    if (batch < 0 || !(tol > 0.0)) return zm::set_error(ZM_EINVAL, "zm_quadcopter_trim_f64: bad argument");
+    const double w0 = wind_body ? wind_body[0] : 0.0, w1 = wind_body ? wind_body[1] : 0.0, w2 = wind_body ? wind_body[2] : 0.0;
+    hipLaunchKernelGGL(zm::quad_trim_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, (hipStream_t)stream, uvw, w0, w1, w2,
+                       xTrim, uTrim, resid, (int*)ok, (long)batch, tol);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }

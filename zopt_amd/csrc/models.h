@@ -4,7 +4,8 @@
 //   ZM_MODEL_LINEAR     x+ = A x + B u            (time-invariant A (n,n), B (n,m) shared by the batch; n <= 12, m <= 4)
 //                       -- the LQ problem of the reference's own iLQR test (tests/test_ilqrUtils.py:167-196)
 //   ZM_MODEL_QUADCOPTER x+ = x + dt * inertialDynamics(x, u)   (zopt/quadcopter.py:116-144 via :70-113, :23-67;
-//                       demos/iterativeLqr.py:35), n = 12, m = 4
+//                       demos/iterativeLqr.py:35), n = 12, m = 4;  dt = 0: x+ := inertialDynamics(x, u) itself
+//   ZM_MODEL_QUADCOPTER_RB  the 8-state rigidBodyDynamics (:70-113) the reference trims and linearises (:146-201), same dt rule
 //   cost                c(x,u) = x^T Q x + u^T R u,  c_f(x) = x^T Qf x   (no 1/2: demos/iterativeLqr.py:12-13,37)
 //
 // The dynamics are templated on the scalar type so that the same code evaluated on dual numbers gives the
@@ -89,28 +90,18 @@ __device__ __forceinline__ Hyper ztan(Hyper a) {
 
 // ---- quadcopter (zopt/quadcopter.py) ---------------------------------------------------------------------------
 // state [u,v,w,p,q,r,phi,theta,psi,x,y,z], control [thrust,mx,my,mz]; g = 9.807, mass = 2.5, I = eye(3) (:15-18).
-// wind = constant wind in the NED frame (:117): the aero forces see uvw - R_b2i^T wind (:138, :64).  The iLQR / MPC demos
-// roll out without wind (demos/iterativeLqr.py:35); their closed-loop simulation uses (3,1,0) (:48).
+// rigidBodyDynamics (:70-113): 8 states [u,v,w,p,q,r,phi,theta], wind given in the BODY frame (the aero forces see uvw - wind, :64)
 template <typename S>
-__device__ __forceinline__ void quad_inertial_dynamics(const S (&x)[12], const S (&u)[4], const double (&wind)[3], S (&xd)[12]) {
+__device__ __forceinline__ void quad_rigid_body(const S (&x)[8], const S (&u)[4], const S (&wb)[3], S (&xd)[8]) {
     constexpr double g = 9.807, mass = 2.5;
     const S cphi = zcos(x[6]), sphi = zsin(x[6]);
     const S cth = zcos(x[7]), sth = zsin(x[7]), tth = ztan(x[7]);
-    const S cpsi = zcos(x[8]), spsi = zsin(x[8]);
-    // R_b2i as written in the reference (:31-37; [0][2] = cphi*sth*cpsi - sphi*spsi, quirk Q4)
-    const S r00 = cth * cpsi, r01 = sphi * sth * cpsi - cphi * spsi, r02 = cphi * sth * cpsi - sphi * spsi;
-    const S r10 = cth * spsi, r11 = sphi * sth * spsi + cphi * cpsi, r12 = cphi * sth * spsi - sphi * cpsi;
-    const S r20 = -sth, r21 = sphi * cth, r22 = cphi * cth;
-    // wind_body = R_b2i^T wind_ned (:138); body velocities wrt the air (:64)
-    const S va0 = x[0] - ((r00 * wind[0] + r10 * wind[1]) + r20 * wind[2]);
-    const S va1 = x[1] - ((r01 * wind[0] + r11 * wind[1]) + r21 * wind[2]);
-    const S va2 = x[2] - ((r02 * wind[0] + r12 * wind[1]) + r22 * wind[2]);
+    const S va0 = x[0] - wb[0], va1 = x[1] - wb[1], va2 = x[2] - wb[2];
     // _getAeroForceMomemnts (:51-67): force = lin * uvw_aero + quad * uvw_aero^2, moment = lin * pqr
     const S fa0 = -0.2 * va0 + -0.05 * (va0 * va0);
     const S fa1 = -0.2 * va1 + -0.05 * (va1 * va1);
     const S fa2 = -0.3 * va2 + -0.1 * (va2 * va2);
     const S ma0 = -0.1 * x[3], ma1 = -0.1 * x[4], ma2 = -0.05 * x[5];
-    // rigidBodyDynamics (:70-113)
     const S d2x = -sth, d2y = sphi * cth, d2z = cphi * cth;                       // :94
     const S ft0 = (fa0 + (mass * g) * d2x);                                       // force_control = m*[0,0,-thrust]
     const S ft1 = (fa1 + (mass * g) * d2y);
@@ -125,10 +116,30 @@ __device__ __forceinline__ void quad_inertial_dynamics(const S (&x)[12], const S
     xd[3] = u[1] + ma0;                                                           // :107 (I = eye: cross(pqr,pqr) = 0)
     xd[4] = u[2] + ma1;
     xd[5] = u[3] + ma2;
-    // body rates -> Euler rates (:41-48, :108, :141)
+    // body rates -> Euler rates, first two rows (:41-48, :108)
     xd[6] = (x[3] + (sphi * tth) * x[4]) + (cphi * tth) * x[5];
     xd[7] = cphi * x[4] - sphi * x[5];
-    xd[8] = (sphi / cth) * x[4] + (cphi / cth) * x[5];
+}
+
+// inertialDynamics (:116-144): wind = constant wind in the NED frame (:117), seen by the rigid body as R_b2i^T wind (:138).  The
+// iLQR / MPC demos roll out without wind (demos/iterativeLqr.py:35); their closed-loop simulation uses (3,1,0) (:48).
+template <typename S>
+__device__ __forceinline__ void quad_inertial_dynamics(const S (&x)[12], const S (&u)[4], const double (&wind)[3], S (&xd)[12]) {
+    const S cphi = zcos(x[6]), sphi = zsin(x[6]);
+    const S cth = zcos(x[7]), sth = zsin(x[7]);
+    const S cpsi = zcos(x[8]), spsi = zsin(x[8]);
+    // R_b2i as written in the reference (:31-37; [0][2] = cphi*sth*cpsi - sphi*spsi, quirk Q4)
+    const S r00 = cth * cpsi, r01 = sphi * sth * cpsi - cphi * spsi, r02 = cphi * sth * cpsi - sphi * spsi;
+    const S r10 = cth * spsi, r11 = sphi * sth * spsi + cphi * cpsi, r12 = cphi * sth * spsi - sphi * cpsi;
+    const S r20 = -sth, r21 = sphi * cth, r22 = cphi * cth;
+    const S wb[3] = {(r00 * wind[0] + r10 * wind[1]) + r20 * wind[2], (r01 * wind[0] + r11 * wind[1]) + r21 * wind[2],
+                     (r02 * wind[0] + r12 * wind[1]) + r22 * wind[2]};
+    const S x8[8] = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]};
+    S xd8[8];
+    quad_rigid_body<S>(x8, u, wb, xd8);                                           // state[:9] -> the 8 states it reads (quirk Q5)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xd[i] = xd8[i];
+    xd[8] = (sphi / cth) * x[4] + (cphi / cth) * x[5];                            // psiDot (:141)
     // xyzDot = R_b2i @ uvw (:142)
     xd[9] = (r00 * x[0] + r01 * x[1]) + r02 * x[2];
     xd[10] = (r10 * x[0] + r11 * x[1]) + r12 * x[2];
@@ -142,7 +153,16 @@ __device__ __forceinline__ void model_step(const zm_model_t& md, const S (&x)[MA
         S xd[12];
         quad_inertial_dynamics<S>(x, u, md.wind_ned, xd);
 #pragma unroll
-        for (int i = 0; i < 12; ++i) xn[i] = x[i] + md.dt * xd[i];
+        for (int i = 0; i < 12; ++i) xn[i] = (md.dt == 0.0) ? xd[i] : x[i] + md.dt * xd[i];   // dt = 0: the derivative itself
+    } else if (md.kind == ZM_MODEL_QUADCOPTER_RB) {
+        const S x8[8] = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]};
+        const S wb[3] = {x[0] * 0.0 + md.wind_ned[0], x[0] * 0.0 + md.wind_ned[1], x[0] * 0.0 + md.wind_ned[2]};   // body-frame wind
+        S xd8[8];
+        quad_rigid_body<S>(x8, u, wb, xd8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xn[i] = (md.dt == 0.0) ? xd8[i] : x[i] + md.dt * xd8[i];
+#pragma unroll
+        for (int i = 8; i < MAXN; ++i) xn[i] = x[i] * 0.0;
     } else {  // ZM_MODEL_LINEAR: A @ x + B @ u
         const int n = md.n, m = md.m;
 #pragma unroll

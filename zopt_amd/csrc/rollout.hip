@@ -154,6 +154,9 @@ static int rollout_impl(const zm_model_t* model, const zm_quadcost_t* cost, cons
     if (md.kind == ZM_MODEL_QUADCOPTER) {
         md.n = 12;
         md.m = 4;
+    } else if (md.kind == ZM_MODEL_QUADCOPTER_RB) {
+        md.n = 8;
+        md.m = 4;
     } else if (md.kind == ZM_MODEL_LINEAR) {
         if (!md.A || !md.B) return zm::set_error(ZM_EINVAL, "zm_rollout_linesearch_f64: linear model needs A, B");
     } else {

@@ -15,6 +15,7 @@ from . import _arrays as arr
 
 ZM_MODEL_LINEAR = 1
 ZM_MODEL_QUADCOPTER = 2
+ZM_MODEL_QUADCOPTER_RB = 3
 
 
 class zm_model_t(ctypes.Structure):
@@ -99,3 +100,63 @@ class QuadraticCost:
         if self._dev is None:
             self._dev = tuple(arr.to_device(X, torch.float64) for X in (self.Q, self.R, self.Qf))
         return zm_quadcost_t(*[t.data_ptr() for t in self._dev])
+
+
+class QuadcopterRigidBody:
+    """The 8-state model the reference trims and linearises: `rigidBodyDynamics(state, control, wind_body)`
+    (quadcopter.py:70-113), state [u,v,w,p,q,r,phi,theta].  dt = 0: the continuous derivative; dt > 0: one Euler step."""
+    n, m = 8, 4
+
+    def __init__(self, dt: float = 0.0, wind_body=(0.0, 0.0, 0.0)):
+        self.dt = float(dt)
+        self.wind_body = tuple(float(w) for w in wind_body)
+        if len(self.wind_body) != 3:
+            raise ValueError("wind_body must have 3 components")
+
+    def c_struct(self):
+        return zm_model_t(ZM_MODEL_QUADCOPTER_RB, 8, 4, 0, self.dt, None, None, (ctypes.c_double * 3)(*self.wind_body))
+
+
+class Quadcopter:
+    """Mirror of `zopt.quadcopter.Quadcopter` (quadcopter.py:10-201) on the device kernels: same method names and argument order,
+    every array may carry leading batch axes (a family of operating points in one call)."""
+    g, m, I = 9.807, 2.5, np.eye(3)         # quadcopter.py:15-18 (compiled into the device model)
+
+    def rigidBodyDynamics(self, state, control, wind_body=(0.0, 0.0, 0.0)):
+        """xDot (..., 8) of the rigid-body model (quadcopter.py:70-113)."""
+        from .pytrees import AffineDynamics
+        return AffineDynamics.from_function(QuadcopterRigidBody(0.0, wind_body), state, control).f
+
+    def inertialDynamics(self, state, control, wind_ned=(0.0, 0.0, 0.0)):
+        """xDot (..., 12) with position states (quadcopter.py:116-144)."""
+        from .pytrees import AffineDynamics
+        return AffineDynamics.from_function(QuadcopterEuler(0.0, wind_ned), state, control).f
+
+    def trim(self, uvwTrim, tol=1e-9):
+        """Trim at the body velocities uvwTrim (..., 3) (quadcopter.py:146-177) -> (xTrim (..., 8), uTrim (..., 4)).
+        Raises RuntimeError("Trim failed") like the reference when an instance does not reach |rigidBodyDynamics| <= 1e-3."""
+        import torch
+        from . import _arrays as arr
+        from . import _lib
+        v = arr.to_device(uvwTrim, torch.float64)
+        lead = tuple(v.shape[:-1])
+        if v.shape[-1] != 3:
+            raise ValueError("uvwTrim must have shape (..., 3)")
+        v = v.reshape(-1, 3).contiguous()
+        b = v.shape[0]
+        xT = torch.empty((b, 8), dtype=torch.float64, device=v.device)
+        uT = torch.empty((b, 4), dtype=torch.float64, device=v.device)
+        res = torch.empty(b, dtype=torch.float64, device=v.device)
+        rc = _lib.lib().zm_quadcopter_trim_f64(v.data_ptr(), None, xT.data_ptr(), uT.data_ptr(), res.data_ptr(), None, b, float(tol),
+                                               ctypes.c_void_p(arr.stream_ptr(v)))
+        _lib.check(rc, "Quadcopter.trim")
+        if b and float(res.max()) > 1e-3:
+            raise RuntimeError("Trim failed")
+        return arr.result_like(xT.reshape(lead + (8,)), uvwTrim), arr.result_like(uT.reshape(lead + (4,)), uvwTrim)
+
+    def linearize(self, x0, u0, dt=0):
+        """Linearise the rigid-body dynamics about (x0 (..., 8), u0 (..., 4)) (quadcopter.py:179-201): continuous (A, B) for
+        dt = 0, forward-Euler discretised `I + dt A`, `dt B` otherwise."""
+        from .pytrees import AffineDynamics
+        lin = AffineDynamics.from_function(QuadcopterRigidBody(float(dt)), x0, u0)
+        return lin.f_x, lin.f_u
