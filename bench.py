@@ -10,6 +10,10 @@ One "step" = one pass of the hot path over one batch: `batch` independent trajec
         bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line (see README / DESIGN.md "Measurement").
+
+Defaults: 300 timed steps after 50 warm-up steps (56 ms of GPU time).  A step is 0.15 ms, and this GPU needs tens of
+milliseconds under load to leave its idle clock state (measured: 10 warm-up + 50 timed steps -> 174 us per launch,
+50 + 300 -> 147 us), so short runs mostly time the clock ramp.
 """
 import argparse
 import json
@@ -88,8 +92,8 @@ def cpu_baseline(batch, T, n, m, target_seconds=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU (weak scaling)")
     ap.add_argument("--T", type=int, default=50)
     ap.add_argument("--n", type=int, default=12)
