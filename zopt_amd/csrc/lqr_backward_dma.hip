@@ -26,6 +26,8 @@
 #include "tile16_f64.h"
 #include "zm_common.h"
 
+#include <cstdlib>
+
 namespace zm {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -100,7 +102,7 @@ __device__ __forceinline__ void dma_issue(DmaState<N, M, D>& a, char* slot) {
     }
 }
 
-template <int N, int M, int D>
+template <int N, int M, int D, bool G4>
 __global__ __launch_bounds__(64, 4) void lqr_backward_dma_f64(const double* __restrict__ A,
                                                               const double* __restrict__ B,
                                                               const double* __restrict__ Q,
@@ -158,6 +160,7 @@ __global__ __launch_bounds__(64, 4) void lqr_backward_dma_f64(const double* __re
     a.oBR = cA ? (G::OB + (c * M + g) * 8) : cB ? (G::OR + ((c - N) * M + g) * 8) : G::OZ;
     const int oYBw = YBO + (g * M + (c - N)) * 8;           // Y_B[4r+g][c-n]   (+ r*4*M*8), lanes cB
     const int oYBr = YBO + ((cA ? c : 0) * M + g) * 8;      // Y_B[c][g]        A operand of Y_B (-L)
+    const int oYBa = YBO + (g * M + (c & 3)) * 8;           // Y_B[4s+g][c & 3] (+ s*4*M*8): A operand of the 4x4x4 blocks (G4)
     const bool vL = cA;                                     // (g < M always: M == 4)
     double* pL = L + (traj * T + (T - 1)) * nm + g * N + c;
 
@@ -193,18 +196,36 @@ __global__ __launch_bounds__(64, 4) void lqr_backward_dma_f64(const double* __re
             d4 y = zero4();
 #pragma unroll
             for (int s = 0; s < KS; ++s) y = mfma(V[s], f4[s], y);
-            // Y_B = Y[:, n..n+3] -> LDS (transposed read later); off the critical path
+            // Y_B = Y[:, n..n+3] -> LDS (read back transposed for W, and -- G4 -- as the small A operand below)
             if (cB) {
 #pragma unroll
                 for (int s = 0; s < KS; ++s) *(double*)(lds + oYBw + s * (4 * M * 8)) = y[s];
             }
-            // G = Y^T F + [0 ; R]  -> row n+g : [ B^T V A | R + B^T V B ]
-            d4 gacc = zero4();
+            double srow;
+            if constexpr (G4) {
+                // [Sux | Suu] = Y_B^T F + [0 | R]: only 4 of the 16 rows of F^T V F are needed, so instead of 3 full-tile MFMAs
+                // (64 cycles each) the 4 x 16 result is computed as four 4x4 blocks by v_mfma_f64_4x4x4_4b (16 cycles each):
+                // block q = c >> 2 takes B_q[k][j] = F[4s+k][4q+j] -- exactly the registers f4[s] already hold -- and
+                // A_q[u][k] = Y_B[4s+k][u], read back from LDS as Y_B[4s+g][c & 3]; lane (g, c) receives S[g][c].
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                double ya[KS];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) gacc = mfma(y[s], f4[s], gacc);
+                for (int s = 0; s < KS; ++s) ya[s] = *(const double*)(lds + oYBa + s * (4 * M * 8));
+                srow = rm;   // + R under the control columns, + 0.0 from the padding elsewhere
+#pragma unroll
+                for (int s = 0; s < KS; ++s) srow = __builtin_amdgcn_mfma_f64_4x4x4f64(ya[s], f4[s], srow, 0, 0, 0);
+            } else {
+                // G = Y^T F + [0 ; R]  -> row n+g : [ B^T V A | R + B^T V B ]
+                d4 gacc = zero4();
+#pragma unroll
+                for (int s = 0; s < KS; ++s) gacc = mfma(y[s], f4[s], gacc);
+                srow = gacc[KS] + rm;  // (+ R under the control columns, + 0.0 from the padding elsewhere)
+            }
 
             // m x m solve: 4 x 16 tile through LDS, every lane reads Suu (broadcast) and its own RHS column
-            exch[g * 16 + c] = gacc[KS] + rm;  // (+ R under the control columns, + 0.0 from the padding elsewhere)
+            exch[g * 16 + c] = srow;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -251,7 +272,16 @@ template <int N, int M>
 static int launch_dma(const double* A, const double* B, const double* Q, const double* R, double* L, int64_t batch,
                       int T, hipStream_t stream) {
     constexpr int D = 3;
-    hipLaunchKernelGGL((lqr_backward_dma_f64<N, M, D>), dim3((unsigned)batch), dim3(64), 0, stream, A, B, Q, R, L, T);
+    // default: the [Sux | Suu] rows by v_mfma_f64_4x4x4_4b blocks (+2.6 % at steady state); ZOPT_AMD_LQR_G4=0 selects the three
+    // full-tile MFMAs instead (A/B measurements)
+    static const bool g4 = [] {
+        const char* e = getenv("ZOPT_AMD_LQR_G4");
+        return !(e && e[0] == '0');
+    }();
+    if (g4)
+        hipLaunchKernelGGL((lqr_backward_dma_f64<N, M, D, true>), dim3((unsigned)batch), dim3(64), 0, stream, A, B, Q, R, L, T);
+    else
+        hipLaunchKernelGGL((lqr_backward_dma_f64<N, M, D, false>), dim3((unsigned)batch), dim3(64), 0, stream, A, B, Q, R, L, T);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }
