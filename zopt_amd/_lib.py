@@ -11,7 +11,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libzopt_amd.so")
+# ZOPT_AMD_LIB: an alternative build of the same library (A/B measurements of kernel variants), else the in-tree one
+LIB_PATH = os.environ.get("ZOPT_AMD_LIB") or os.path.join(CSRC, "libzopt_amd.so")
 
 ZM_OK = 0
 ZM_EINVAL = -1

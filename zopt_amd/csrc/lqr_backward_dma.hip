@@ -240,7 +240,8 @@ __global__ __launch_bounds__(64, 4) void lqr_backward_dma_f64(const double* __re
             // The solve is a long chain of short dependent VALU ops; without priority each of them can queue behind a
             // 64-cycle MFMA of another wave on the shared fp64 pipe (measured: -3..4 % kernel time).
             __builtin_amdgcn_s_setprio(3);
-            if (!__all(lu_solve4_nopivot(S, b, x))) {
+            // wave-uniform vote on the scalar unit: "some lane failed the growth check" = ballot(!ok) != 0
+            if (__builtin_amdgcn_ballot_w64(!lu_solve4_nopivot(S, b, x)) != 0ull) {
                 // rare: growth check failed somewhere in the wave -> partial pivoting, IEEE division
                 lu_solve4(S, b, x);
             }

@@ -71,16 +71,14 @@ __device__ __forceinline__ void lu_solve4(double (&S)[4][4], double (&b)[4], dou
     }
 }
 
-// 1/a to fp64 accuracy (<= ~1 ulp) from v_rcp_f64 and two Newton steps; ~half the issue cost of the IEEE
-// division sequence.  a = 0, inf, NaN or denormal-range pivots give inf/NaN here -- callers test the result and
-// take the IEEE / pivoted path in that case.
+// 1/a to fp64 accuracy (<= ~1 ulp) from v_rcp_f64 (measured max relative error 4.6e-8, tools/rcp_accuracy.hip) and ONE
+// third-order correction r0 (1 + e + e^2), e = 1 - a r0 (error e^3 ~ 1e-22): three FMAs, one fewer than two Newton steps and
+// as accurate.  a = 0, inf, NaN or denormal-range pivots give inf/NaN here -- callers test the result and take the IEEE /
+// pivoted path in that case.
 __device__ __forceinline__ double fast_rcp(const double a) {
-    double r = __builtin_amdgcn_rcp(a);
-    double e = __builtin_fma(-a, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-a, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(a);
+    const double e = __builtin_fma(-a, r, 1.0);
+    return __builtin_fma(r, __builtin_fma(e, e, e), r);
 }
 
 // Fast path of the m x m solve: Gaussian elimination WITHOUT row exchanges (no register shuffling at all),
