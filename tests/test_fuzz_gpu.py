@@ -1,0 +1,96 @@
+"""Seeded randomised parity sweep over shapes: many small (n, m, T, batch) combinations per entry point against the oracle, to
+catch lane-map / padding corner cases the hand-picked parametrisations miss (ragged n and m, single steps, batches that do not
+fill a wave, batches larger than the SIMD count)."""
+import numpy as np
+import pytest
+
+from oracle import zopt_oracle as zo
+from tests import problems
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import torch
+    assert torch.cuda.is_available()
+    from zopt_amd import ilqrUtils, lqrUtils, pytrees
+    return lqrUtils, ilqrUtils, pytrees
+
+
+def test_lqr_small_shapes_fp64(mods):
+    lqr, _, _ = mods
+    rng = np.random.default_rng(2024)
+    for case in range(60):
+        n, m = int(rng.integers(1, 13)), int(rng.integers(1, 5))
+        T, b = int(rng.integers(1, 8)), int(rng.integers(1, 71))
+        A, B, Q, R = problems.random_time_varying(b, T, n, m, seed=1000 + case)
+        if case % 3 == 0:            # nonsymmetric weights every third case
+            Q = Q + 0.1 * rng.standard_normal(Q.shape)
+            R = R + 0.1 * rng.standard_normal(R.shape)
+        L = lqr.discreteFiniteHorizonLqr(A, B, Q, R, T)
+        assert _rel(L, zo.discreteFiniteHorizonLqr(A, B, Q, R, T)) <= 1e-10, (case, n, m, T, b)
+
+
+def test_lqr_medium_shapes_fp32_and_fp64(mods):
+    lqr, _, _ = mods
+    rng = np.random.default_rng(2025)
+    for case in range(30):
+        n, m = int(rng.integers(13, 65)), int(rng.integers(1, 17))
+        T, b = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+        A, B, Q, R = problems.random_time_varying(b, T, n, m, seed=2000 + case)
+        Lr = zo.discreteFiniteHorizonLqr(A, B, Q, R, T)
+        assert _rel(lqr.discreteFiniteHorizonLqr(A, B, Q, R, T), Lr) <= 1e-10, ("f64", case, n, m, T, b)
+        A32, B32, Q32, R32 = (x.astype(np.float32) for x in (A, B, Q, R))
+        L64 = zo.discreteFiniteHorizonLqr(*(x.astype(np.float64) for x in (A32, B32, Q32, R32)), T)
+        L32 = zo.discreteFiniteHorizonLqr(A32, B32, Q32, R32, T)
+        Lg = lqr.discreteFiniteHorizonLqr(A32, B32, Q32, R32, T)
+        assert np.max(np.abs(Lg - L64)) <= max(2e-4 * np.max(np.abs(L64)), 4 * np.max(np.abs(L32 - L64))), ("f32", case, n, m, T, b)
+
+
+def test_affine_and_ilqr_sweeps(mods):
+    lqr, ilqr, pt = mods
+    rng = np.random.default_rng(2026)
+    for case in range(40):
+        n, m = int(rng.integers(1, 13)), int(rng.integers(1, 5))
+        T, b = int(rng.integers(1, 7)), int(rng.integers(1, 40))
+        (f, f_x, f_u), (c, c_x, c_u, c_xx, c_ux, c_uu), (v, v_x, v_xx) = problems.random_ilqr_model(b, T, n, m, seed=3000 + case)
+        pol = ilqr.backwardPass_ilqr(pt.AffineDynamics(f, f_x, f_u), pt.QuadraticCostFunction(c, c_x, c_u, c_xx, c_ux, c_uu),
+                                     pt.QuadraticValueFunction(v, v_x, v_xx))
+        for i in range(min(b, 3)):
+            ref = zo.backwardPass_ilqr(zo.AffineDynamics(f[i], f_x[i], f_u[i]),
+                                       zo.QuadraticCostFunction(c[i], c_x[i], c_u[i], c_xx[i], c_ux[i], c_uu[i]),
+                                       zo.QuadraticValueFunction(v[i], v_x[i], v_xx[i]))
+            assert _rel(pol.L[i], ref.L) <= 1e-9 and _rel(pol.l[i], ref.l) <= 1e-9, ("ilqr", case, n, m, T, b)
+        # bilinear / affine LQR on the same random data: d = f, H = c_ux, q = c_x, r = c_u
+        q0 = rng.standard_normal((b, T))
+        Lg, lg = lqr.bilinearAffineLqr(f_x, f_u, f, c_xx, c_uu, c_ux, c_x, c_u, q0, T)
+        for i in range(min(b, 3)):
+            Lr, lr = zo.bilinearAffineLqr(f_x[i], f_u[i], f[i], c_xx[i], c_uu[i], c_ux[i], c_x[i], c_u[i], q0[i], T)
+            assert _rel(Lg[i], Lr) <= 1e-9 and _rel(lg[i], lr) <= 1e-9, ("affine", case, n, m, T, b)
+
+
+def test_dare_and_psd_sweeps(mods):
+    lqr, ilqr, _ = mods
+    rng = np.random.default_rng(2027)
+    for case in range(20):
+        n, m, b = int(rng.integers(1, 13)), int(rng.integers(1, 5)), int(rng.integers(1, 9))
+        A, B, Q, R = problems.random_lti_systems(b, n, m, seed=4000 + case, rho=float(rng.uniform(0.5, 1.2)))
+        L = lqr.discreteInfiniteHorizonLqr(A, B, Q, R)
+        for i in range(b):
+            Lr, _ = zo.discreteInfiniteHorizonLqr(A[i], B[i], Q[i], R[i])
+            assert _rel(L[i], Lr) <= 1e-9, ("dare", case, n, m, i)
+    for case in range(20):
+        k, b = int(rng.integers(1, 17)), int(rng.integers(1, 30))
+        M = rng.standard_normal((b, k, k))
+        Amat = M + np.swapaxes(M, -1, -2)
+        if case % 2:
+            Amat[:, :, k // 2] = 0; Amat[:, k // 2, :] = 0            # exact zero row / column: rank-deficient input
+        P = ilqr.ensurePositiveDefinite(Amat)
+        w, vv = np.linalg.eigh(Amat)
+        ref = (vv * np.maximum(w, 1e-3)[:, None, :]) @ np.swapaxes(vv, -1, -2)
+        assert np.max(np.abs(P - ref)) <= 1e-11 * max(1.0, np.max(np.abs(ref))), ("psd", case, k, b)
