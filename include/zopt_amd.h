@@ -137,15 +137,16 @@ int zm_rollout_linesearch_f64(const zm_model_t* model, const zm_quadcost_t* cost
 
 /* Same, over a compacted list of trajectory ids: only list[0..count) are processed (densely packed into waves), all
  * other trajectories keep their outputs.  Arrays keep their full (batch, ...) shapes and are indexed by trajectory id.
- * Used by the iLQR / DDP drivers once most of the batch has converged (a mask would leave mostly idle waves). */
+ * Used by the iLQR / DDP drivers once most of the batch has converged (a mask would leave mostly idle waves).  `active`
+ * (batch) int32 or NULL: listed trajectories with active == 0 are skipped as well, so a list may be a few iterations old. */
 int zm_rollout_linesearch_list_f64(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0, const double* l,
                                    const double* L, const double* xPrev, const double* uPrev, const double* alphas,
-                                   int n_alpha, const int32_t* list, int64_t count, double* xTraj, double* uTraj, double* J,
-                                   int32_t* alpha_idx, int64_t batch, int T, void* stream);
+                                   int n_alpha, const int32_t* list, int64_t count, const int32_t* active, double* xTraj,
+                                   double* uTraj, double* J, int32_t* alpha_idx, int64_t batch, int T, void* stream);
 
 /* Acceptance step of the iLQR / DDP loop (zopt/ilqrUtils.py:316-320) for the trajectories in list[0..count):
  *     converged = |J - Jn| <= tol;  J <- Jn;  xTraj <- xTrajNew;  uTraj <- uTrajNew;  active <- !converged
- * Arrays keep their (batch, ...) shapes; rows of trajectories not listed are left untouched. */
+ * Arrays keep their (batch, ...) shapes; rows of trajectories not listed -- or listed but with active == 0 -- are left untouched. */
 int zm_ilqr_accept_f64(const int32_t* list, int64_t count, double* J, const double* Jn, double* xTraj, const double* xTrajNew,
                        double* uTraj, const double* uTrajNew, int32_t* converged, int32_t* active, double tol, int64_t batch,
                        int T, int n, int m, void* stream);

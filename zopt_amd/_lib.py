@@ -39,7 +39,7 @@ SYMBOLS = {
     # (model*, cost*, x0, l, L, xPrev, uPrev, alphas, n_alpha, active, xTraj, uTraj, J, alpha_idx, batch, T, stream)
     "zm_rollout_linesearch_f64": (ctypes.c_int, [_c_dp] * 8 + [ctypes.c_int] + [_c_dp] * 5 +
                                   [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
-    "zm_rollout_linesearch_list_f64": (ctypes.c_int, [_c_dp] * 8 + [ctypes.c_int] + [_c_dp] + [ctypes.c_int64] + [_c_dp] * 4 +
+    "zm_rollout_linesearch_list_f64": (ctypes.c_int, [_c_dp] * 8 + [ctypes.c_int] + [_c_dp] + [ctypes.c_int64] + [_c_dp] * 5 +
                                        [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "zm_ilqr_accept_f64": (ctypes.c_int, [_c_dp, ctypes.c_int64] + [_c_dp] * 8 + [ctypes.c_double, ctypes.c_int64, ctypes.c_int,
                                                                            ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),

@@ -91,11 +91,12 @@ __device__ __forceinline__ Hyper ztan(Hyper a) {
 // ---- quadcopter (zopt/quadcopter.py) ---------------------------------------------------------------------------
 // state [u,v,w,p,q,r,phi,theta,psi,x,y,z], control [thrust,mx,my,mz]; g = 9.807, mass = 2.5, I = eye(3) (:15-18).
 // rigidBodyDynamics (:70-113): 8 states [u,v,w,p,q,r,phi,theta], wind given in the BODY frame (the aero forces see uvw - wind, :64)
+// (the trigonometric values are passed in: inertialDynamics needs them too, and on dual / hyper-dual numbers they are the
+// expensive part of the model)
 template <typename S>
-__device__ __forceinline__ void quad_rigid_body(const S (&x)[8], const S (&u)[4], const S (&wb)[3], S (&xd)[8]) {
+__device__ __forceinline__ void quad_rigid_body_trig(const S (&x)[8], const S (&u)[4], const S (&wb)[3], const S cphi, const S sphi,
+                                                     const S cth, const S sth, const S tth, S (&xd)[8]) {
     constexpr double g = 9.807, mass = 2.5;
-    const S cphi = zcos(x[6]), sphi = zsin(x[6]);
-    const S cth = zcos(x[7]), sth = zsin(x[7]), tth = ztan(x[7]);
     const S va0 = x[0] - wb[0], va1 = x[1] - wb[1], va2 = x[2] - wb[2];
     // _getAeroForceMomemnts (:51-67): force = lin * uvw_aero + quad * uvw_aero^2, moment = lin * pqr
     const S fa0 = -0.2 * va0 + -0.05 * (va0 * va0);
@@ -120,13 +121,17 @@ __device__ __forceinline__ void quad_rigid_body(const S (&x)[8], const S (&u)[4]
     xd[6] = (x[3] + (sphi * tth) * x[4]) + (cphi * tth) * x[5];
     xd[7] = cphi * x[4] - sphi * x[5];
 }
+template <typename S>
+__device__ __forceinline__ void quad_rigid_body(const S (&x)[8], const S (&u)[4], const S (&wb)[3], S (&xd)[8]) {
+    quad_rigid_body_trig<S>(x, u, wb, zcos(x[6]), zsin(x[6]), zcos(x[7]), zsin(x[7]), ztan(x[7]), xd);
+}
 
 // inertialDynamics (:116-144): wind = constant wind in the NED frame (:117), seen by the rigid body as R_b2i^T wind (:138).  The
 // iLQR / MPC demos roll out without wind (demos/iterativeLqr.py:35); their closed-loop simulation uses (3,1,0) (:48).
 template <typename S>
 __device__ __forceinline__ void quad_inertial_dynamics(const S (&x)[12], const S (&u)[4], const double (&wind)[3], S (&xd)[12]) {
     const S cphi = zcos(x[6]), sphi = zsin(x[6]);
-    const S cth = zcos(x[7]), sth = zsin(x[7]);
+    const S cth = zcos(x[7]), sth = zsin(x[7]), tth = ztan(x[7]);
     const S cpsi = zcos(x[8]), spsi = zsin(x[8]);
     // R_b2i as written in the reference (:31-37; [0][2] = cphi*sth*cpsi - sphi*spsi, quirk Q4)
     const S r00 = cth * cpsi, r01 = sphi * sth * cpsi - cphi * spsi, r02 = cphi * sth * cpsi - sphi * spsi;
@@ -136,7 +141,7 @@ __device__ __forceinline__ void quad_inertial_dynamics(const S (&x)[12], const S
                      (r02 * wind[0] + r12 * wind[1]) + r22 * wind[2]};
     const S x8[8] = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]};
     S xd8[8];
-    quad_rigid_body<S>(x8, u, wb, xd8);                                           // state[:9] -> the 8 states it reads (quirk Q5)
+    quad_rigid_body_trig<S>(x8, u, wb, cphi, sphi, cth, sth, tth, xd8);           // state[:9] -> the 8 states it reads (quirk Q5)
 #pragma unroll
     for (int i = 0; i < 8; ++i) xd[i] = xd8[i];
     xd[8] = (sphi / cth) * x[4] + (cphi / cth) * x[5];                            // psiDot (:141)

@@ -206,11 +206,11 @@ extern "C" int zm_rollout_linesearch_f64(const zm_model_t* model, const zm_quadc
 extern "C" int zm_rollout_linesearch_list_f64(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0,
                                               const double* l, const double* L, const double* xPrev, const double* uPrev,
                                               const double* alphas, int n_alpha, const int32_t* list, int64_t count,
-                                              double* xTraj, double* uTraj, double* J, int32_t* alpha_idx, int64_t batch, int T,
-                                              void* stream) {
+                                              const int32_t* active, double* xTraj, double* uTraj, double* J, int32_t* alpha_idx,
+                                              int64_t batch, int T, void* stream) {
     if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     if (!list) return zm::set_error(ZM_EINVAL, "zm_rollout_linesearch_list_f64: null list");
-    return rollout_impl(model, cost, x0, l, L, xPrev, uPrev, alphas, n_alpha, nullptr, list, count, xTraj, uTraj, J, alpha_idx,
+    return rollout_impl(model, cost, x0, l, L, xPrev, uPrev, alphas, n_alpha, active, list, count, xTraj, uTraj, J, alpha_idx,
                         batch, T, stream);
 }
 
@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void ilqr_accept_kernel(const int* __restrict_
     const long slot = blockIdx.x;
     if (slot >= count) return;
     const long t = list[slot];
+    if (active[t] == 0) return;   // the list may be older than the mask (it is rebuilt only every few iterations)
     for (long e = threadIdx.x; e < xrow; e += blockDim.x) xT[t * xrow + e] = xT2[t * xrow + e];
     for (long e = threadIdx.x; e < urow; e += blockDim.x) uT[t * urow + e] = uT2[t * urow + e];
     if (threadIdx.x == 0) {

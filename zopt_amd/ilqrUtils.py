@@ -405,8 +405,14 @@ def _ilqr_or_ddp(dynamics, runningCost, terminalCost, x0, uGuess, maxIter, tol, 
     converged = torch.zeros(B, dtype=torch.int32, device=dev)
     active = torch.ones(B, dtype=torch.int32, device=dev)
     it = 0
-    while it < maxIter and bool(active.any()):                                                        # (:301-303)
-        # (the .any() above is this iteration's one host sync; nonzero() below reuses the same completed mask)
+    ids = None
+    SYNC = 1   # host synchronisation (termination test + rebuild of the compacted id list) every SYNC iterations; in between the
+               # kernels run on the device-side mask alone -- an iteration over a fully converged batch touches nothing
+    while it < maxIter:                                                                               # (:301-303)
+        if it % SYNC == 0:
+            if not bool(active.any()):
+                break
+            ids = torch.nonzero(active).flatten().to(torch.int32)
         ap = active.data_ptr()
         _lib.check(lib.zm_linearize_dynamics_f64(pmd, xT.data_ptr(), uT.data_ptr(), ap, None, f_x.data_ptr(),
                                                  f_u.data_ptr(), B, N, st), "iterativeLqr: linearize")
@@ -425,11 +431,10 @@ def _ilqr_or_ddp(dynamics, runningCost, terminalCost, x0, uGuess, maxIter, tol, 
                                                    c_xx.data_ptr(), c_ux.data_ptr(), c_uu.data_ptr(), v_x.data_ptr(),
                                                    v_xx.data_ptr(), ap, 1, l.data_ptr(), L.data_ptr(), B, N, n, m, st),
                        "iterativeLqr: backward pass")
-        # the 16-way line search packs 4 trajectories per wave: with a mask most waves would idle once most of the batch
-        # has converged, so the still-active trajectories go in as a compacted id list
-        ids = torch.nonzero(active).flatten().to(torch.int32)
+        # the 16-way line search packs 4 trajectories per wave: with a mask alone most waves would idle once most of the batch
+        # has converged, so the still-active trajectories go in as a compacted id list (checked against the mask in the kernel)
         _lib.check(lib.zm_rollout_linesearch_list_f64(pmd, pcs, dx0.data_ptr(), l.data_ptr(), L.data_ptr(), xT.data_ptr(),
-                                                      uT.data_ptr(), alphas.data_ptr(), 16, ids.data_ptr(), int(ids.numel()),
+                                                      uT.data_ptr(), alphas.data_ptr(), 16, ids.data_ptr(), int(ids.numel()), ap,
                                                       xT2.data_ptr(), uT2.data_ptr(), Jn.data_ptr(), None, B, N, st),
                    "iterativeLqr: forward pass")
         # accept: converged = |J - J_new| <= tol, (traj, J) <- (traj_new, J_new) on the listed rows only             (:316-320)
