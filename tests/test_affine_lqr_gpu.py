@@ -84,3 +84,35 @@ def test_no_batch_axis_and_torch(lqr):
     t = [torch.as_tensor(x, device="cuda") for x in args]
     Lt, lt = lqr.bilinearAffineLqr(*t, 9)
     assert Lt.is_cuda and _rel(Lt.cpu().numpy()[0], Lr) <= 1e-10
+
+
+@pytest.mark.parametrize("n,T", [(12, 1), (12, 2), (12, 3), (12, 50), (8, 1), (8, 2), (8, 3), (8, 100)])
+def test_dma_ring_and_register_kernels_agree(n, T):
+    """zm_lqr_backward_affine_f64 stages (n in {8, 12}, m = 4, 16-B aligned operands) through an LDS ring by DMA and
+    runs every other case with register prefetch: both against the oracle, on every ring phase (T around the ring
+    depth); the register kernel is reached by handing the same data over at 8-B-aligned addresses."""
+    import ctypes
+    import torch
+    from zopt_amd import _lib
+    m, batch = 4, 7
+    A, B, d, Q, R, H, q, r, q0 = _problem(batch, T, n, m, seed=31 * n + T, nonsym=True)
+    Lr, lr = zo.bilinearAffineLqr(A, B, d, Q, R, H, q, r, q0, T)
+    outs = []
+    for shift in (0, 1):
+        dev = []
+        for X in (A, B, d, Q, R, H, q, r):
+            buf = torch.zeros(X.size + 2, dtype=torch.float64, device="cuda")
+            buf[shift:shift + X.size] = torch.as_tensor(np.ascontiguousarray(X).ravel(), device="cuda")
+            t = buf[shift:shift + X.size]
+            assert t.data_ptr() % 16 == 8 * shift
+            dev.append(t)
+        dL = torch.empty((batch, T, m, n), dtype=torch.float64, device="cuda")
+        dl = torch.empty((batch, T, m), dtype=torch.float64, device="cuda")
+        rc = _lib.lib().zm_lqr_backward_affine_f64(*[t.data_ptr() for t in dev], dL.data_ptr(), dl.data_ptr(), batch, T, n, m,
+                                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "zm_lqr_backward_affine_f64")
+        torch.cuda.synchronize()
+        L, l = dL.cpu().numpy(), dl.cpu().numpy()
+        assert _rel(L, Lr) <= 1e-10 and _rel(l, lr) <= 1e-10
+        outs.append((L, l))
+    assert _rel(outs[0][0], outs[1][0]) <= 1e-12 and _rel(outs[0][1], outs[1][1]) <= 1e-12

@@ -159,3 +159,53 @@ def test_riccatiStep_known_answers_and_value_function():
             assert abs(Vd.v[i] - Vr.v) <= 1e-9 * max(1.0, abs(Vr.v))
             assert _rel(Vd.v_x[i], Vr.v_x) <= 1e-9 and _rel(Vd.v_xx[i], Vr.v_xx) <= 1e-9
             assert _rel(pd.l[i], pr.l) <= 1e-9 and _rel(pd.L[i], pr.L) <= 1e-9
+
+
+@pytest.mark.parametrize("n,T", [(12, 1), (12, 2), (12, 3), (12, 4), (12, 7), (12, 100), (8, 1), (8, 2), (8, 5), (8, 33)])
+@pytest.mark.parametrize("shared", [False, True])
+def test_dma_ring_and_register_kernels_agree(n, T, shared):
+    """zm_ilqr_backward_ex_f64 stages (n in {8, 12}, m = 4, 16-B aligned operands) through an LDS ring by DMA and runs
+    every other case with register prefetch: both against the oracle, on every ring phase (T around the ring depth 3),
+    with per-step and shared (time-invariant) Hessians and an active mask; the register kernel is reached by handing
+    the same data over at 8-B-aligned addresses."""
+    import ctypes
+    import torch
+    from zopt_amd import _lib
+    m, batch = 4, 9
+    dyn, cost, Vf = problems.random_ilqr_model(batch, T, n, m, seed=7 * n + T)
+    c, c_x, c_u, c_xx, c_ux, c_uu = cost
+    v, v_x, v_xx = Vf
+    if shared:   # one Hessian (and terminal Hessian) for every trajectory and step
+        c_xx = np.broadcast_to(c_xx[0, 0], c_xx.shape).copy()
+        c_ux = np.broadcast_to(c_ux[0, 0], c_ux.shape).copy()
+        c_uu = np.broadcast_to(c_uu[0, 0], c_uu.shape).copy()
+        v_xx = np.broadcast_to(v_xx[0], v_xx.shape).copy()
+    ref = zo.backwardPass_ilqr(zo.AffineDynamics(*dyn), zo.QuadraticCostFunction(c, c_x, c_u, c_xx, c_ux, c_uu),
+                               zo.QuadraticValueFunction(v, v_x, v_xx))
+    act = np.ones(batch, dtype=np.int32)
+    act[[2, 5]] = 0
+    host = [dyn[1], dyn[2], c_x, c_u] + ([c_xx[0, 0], c_ux[0, 0], c_uu[0, 0]] if shared else [c_xx, c_ux, c_uu]) + \
+           [v_x, v_xx[0] if shared else v_xx]
+    dact = torch.as_tensor(act, device="cuda")
+    outs = []
+    for shift in (0, 1):    # 0: 16-B aligned (DMA ring); 1: every operand at +8 B (register kernel)
+        dev = []
+        for X in host:
+            buf = torch.zeros(X.size + 2, dtype=torch.float64, device="cuda")
+            buf[shift:shift + X.size] = torch.as_tensor(np.ascontiguousarray(X).ravel(), device="cuda")
+            t = buf[shift:shift + X.size]
+            assert t.data_ptr() % 16 == 8 * shift
+            dev.append(t)
+        dl = torch.full((batch, T, m), 77.0, dtype=torch.float64, device="cuda")
+        dL = torch.full((batch, T, m, n), 77.0, dtype=torch.float64, device="cuda")
+        rc = _lib.lib().zm_ilqr_backward_ex_f64(*[t.data_ptr() for t in dev], dact.data_ptr(), 1 if shared else 0,
+                                                dl.data_ptr(), dL.data_ptr(), batch, T, n, m,
+                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "zm_ilqr_backward_ex_f64")
+        torch.cuda.synchronize()
+        l, L = dl.cpu().numpy(), dL.cpu().numpy()
+        on = act == 1
+        assert np.all(l[~on] == 77.0) and np.all(L[~on] == 77.0)      # masked trajectories keep their policy
+        assert _rel(L[on], ref.L[on]) <= RTOL and _rel(l[on], ref.l[on]) <= RTOL
+        outs.append((l, L))
+    assert _rel(outs[0][1], outs[1][1]) <= 1e-12 and _rel(outs[0][0], outs[1][0]) <= 1e-12

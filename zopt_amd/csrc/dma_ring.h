@@ -1,0 +1,47 @@
+// LDS ring filled by DMA (global_load_lds): the pieces shared by the kernels that stage their per-step operands this way
+// (lqr_backward_dma.hip, ilqr_backward.hip).  Every DMA wave-instruction copies 64 x 16 B, lane i -> LDS bytes [16 i, 16 i + 16).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace zm {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+// 16 B of zeros: DMA source of the idle lanes, so that every ring slot's padding reads 0.0.
+static __device__ __attribute__((aligned(16))) const double zm_zero_src[2] = {0.0, 0.0};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_imm() {
+    static_assert(N >= 0 && N <= 12, "vmcnt immediate");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+
+// DMA groups retire in issue order and are issued in decreasing step order, so when step j is consumed exactly
+// min(D-1, j) younger groups may still be in flight.  (The L_k stores are NOT counted: that only over-waits.)
+template <int NI, int D>
+__device__ __forceinline__ void wait_for_step(const int j) {
+    if (j >= D - 1) {
+        wait_vmcnt_imm<NI*(D - 1)>();
+    } else if (D >= 3 && j == 1) {
+        wait_vmcnt_imm<NI>();
+    } else if (D >= 4 && j == 2) {
+        wait_vmcnt_imm<2 * NI>();
+    } else {
+        wait_vmcnt_imm<0>();
+    }
+}
+
+}  // namespace zm

@@ -35,9 +35,12 @@
 // (v0 / q0 never influence L or l and are not carried.)  V d is a row reduction of the V registers (4 xor-shuffles per
 // K-step), V^T d a column reduction (2 shuffles) re-laid out through LDS; both are kept apart so that a
 // nonsymmetric V is treated exactly as the reference does.
+#include "dma_ring.h"
 #include "jacobi16.h"
 #include "tile16_f64.h"
 #include "zm_common.h"
+
+#include <cstdlib>
 
 namespace zm {
 
@@ -437,6 +440,219 @@ __global__ __launch_bounds__(64, 2) void ilqr_backward_t16_f64(
 
 }  // namespace zm
 
+// ---------------------------------------------------------------------------------------------------------------------
+// K3-DMA: the iLQR sweep (MODE 0) with its per-step operands staged through an LDS ring by DMA, as K1 does
+// (lqr_backward_dma.hip): no operand prefetch registers, no per-step address arithmetic for loads, no vector-memory
+// latency on the chain.  n in {8, 12}, m = 4, 16-B aligned pointers; every other case runs ilqr_backward_t16_f64.
+// Slot image of one step (16-B chunks): f_x | f_u | c_x | c_u [| c_xx | c_ux | c_uu unless the Hessians are shared] | zeros.
+namespace zm {
+
+template <int N, int M, bool SHARED, int MODE>
+struct IlqrDmaGeom {
+    static constexpr int KS = N / 4;
+    static constexpr int CFX = N * N / 2, CFU = N * M / 2, CCX = N / 2, CCU = M / 2;
+    static constexpr int CXX = SHARED ? 0 : N * N / 2, CUX = SHARED ? 0 : N * M / 2, CUU = SHARED ? 0 : M * M / 2;
+    static constexpr int CD = (MODE == 1) ? N / 2 : 0;   // MODE 1: the affine term d of the dynamics
+    static constexpr int CT = CFX + CFU + CCX + CCU + CXX + CUX + CUU + CD;
+    static constexpr int NI = (CT + 63) / 64;
+    static constexpr int SLOT = NI * 1024;
+    static constexpr int OFX = 0, OFU = CFX * 16, OCX = OFU + CFU * 16, OCU = OCX + CCX * 16;
+    static constexpr int OXX = OCU + CCU * 16, OUX = OXX + CXX * 16, OUU = OUX + CUX * 16;
+    static constexpr int OD = OUU + CUU * 16;
+    static constexpr int OZ = CT * 16;
+    static_assert(N % 4 == 0 && N >= 8 && N <= 12 && M == 4, "fast path: all K-step rows live, m = 4");
+    static_assert(MODE == 0 || (MODE == 1 && !SHARED), "sweeps without second-order dynamics");
+    static_assert(SLOT - OZ >= 16, "slot needs zero padding");
+};
+
+template <int N, int M, int D, bool SHARED, int MODE>
+__global__ __launch_bounds__(64, 3) void ilqr_backward_dma_f64(
+    const double* __restrict__ f_x, const double* __restrict__ f_u, const double* __restrict__ c_x,
+    const double* __restrict__ c_u, const double* __restrict__ c_xx, const double* __restrict__ c_ux,
+    const double* __restrict__ c_uu, const double* __restrict__ vf_x, const double* __restrict__ vf_xx,
+    const double* __restrict__ dvec, const long svx, const long svxx, const int* __restrict__ active,
+    double* __restrict__ lout, double* __restrict__ Lout, const int T) {
+    using G = IlqrDmaGeom<N, M, SHARED, MODE>;
+    constexpr int KS = G::KS, NI = G::NI, SLOT = G::SLOT, NP = N;
+    constexpr int nn = N * N, nm = N * M, mm = M * M;
+    constexpr int SMO = D * SLOT;
+    __shared__ __attribute__((aligned(16))) char lds[SMO + ILQR_LDS_DOUBLES * 8];
+    double* sm = (double*)(lds + SMO);
+    const int lane = threadIdx.x;
+    const long traj = blockIdx.x;
+    if (active && active[traj] == 0) return;   // whole wave leaves: this trajectory keeps its previous policy
+    const int g = lane >> 4, c = lane & 15;
+    const bool cA = c < N, cB = (c >= N) && (c < N + M);
+
+    // DMA sources: chunk q of the step image -> (array, offset)
+    const char* p[NI];
+    int st[NI];
+    {
+        const long last = traj * T + (T - 1);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int q = i * 64 + lane;
+            const char* src = (const char*)zm_zero_src;
+            int stride = 0;
+            if (q < G::CFX) {
+                src = (const char*)(f_x + last * nn) + q * 16;  stride = nn * 8;
+            } else if ((q -= G::CFX) < G::CFU) {
+                src = (const char*)(f_u + last * nm) + q * 16;  stride = nm * 8;
+            } else if ((q -= G::CFU) < G::CCX) {
+                src = (const char*)(c_x + last * N) + q * 16;   stride = N * 8;
+            } else if ((q -= G::CCX) < G::CCU) {
+                src = (const char*)(c_u + last * M) + q * 16;   stride = M * 8;
+            } else if constexpr (!SHARED) {
+                if ((q -= G::CCU) < G::CXX) {
+                    src = (const char*)(c_xx + last * nn) + q * 16;  stride = nn * 8;
+                } else if ((q -= G::CXX) < G::CUX) {
+                    src = (const char*)(c_ux + last * nm) + q * 16;  stride = nm * 8;
+                } else if ((q -= G::CUX) < G::CUU) {
+                    src = (const char*)(c_uu + last * mm) + q * 16;  stride = mm * 8;
+                } else if constexpr (MODE == 1) {
+                    if ((q -= G::CUU) < G::CD) {
+                        src = (const char*)(dvec + last * N) + q * 16;  stride = N * 8;
+                    }
+                }
+            }
+            p[i] = src;
+            st[i] = stride;
+        }
+    }
+    auto dma = [&](char* slot) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_void_t*)p[i], (lds_void_t*)(slot + i * 1024), 16, 0, 0);
+            p[i] -= st[i];
+        }
+    };
+    // LDS offsets of this lane's operands inside a slot (lanes outside a matrix read the zero padding)
+    const int oF = cA ? (G::OFX + (g * N + c) * 8) : cB ? (G::OFU + (g * M + (c - N)) * 8) : G::OZ;
+    const int dF = cA ? 4 * N * 8 : cB ? 4 * M * 8 : 0;
+    const int ocv = cA ? (G::OCX + c * 8) : cB ? (G::OCU + (c - N) * 8) : G::OZ;
+    const int oC = cA ? (G::OXX + (g * N + c) * 8) : G::OZ;       // !SHARED only
+    const int dC = cA ? 4 * N * 8 : 0;
+    const int oCu = cA ? (G::OUX + (g * N + c) * 8) : cB ? (G::OUU + (g * M + (c - N)) * 8) : G::OZ;   // (g < M always)
+    const int odc = cA ? (G::OD + c * 8) : G::OZ;                  // MODE 1: d[c]; d[4 s + g] is read at OD + (4 s + g) 8
+
+    // the pieces of IlqrAddr the step still uses: outputs and lane roles
+    IlqrAddr<KS> a;
+    a.cA = cA;
+    a.vL = cA;                                  // (g < m always: M == 4)
+    const bool vl = (c == NP);
+    a.vOut = a.vL || vl;
+    {
+        const long last = traj * T + (T - 1);
+        a.pOut = a.vL ? (Lout + last * nm + g * N + c) : (lout + last * M + g);
+    }
+    a.sOut = vl ? M : nm;
+    const bool rhs_qu = (c == NP);
+    const int ob0 = rhs_qu ? (64 + NP + 0) : (0 * 16 + c);
+    const int ob1 = rhs_qu ? (64 + NP + 1) : (1 * 16 + c);
+    const int ob2 = rhs_qu ? (64 + NP + 2) : (2 * 16 + c);
+    const int ob3 = rhs_qu ? (64 + NP + 3) : (3 * 16 + c);
+    const int oqa = (c < 4) ? (c * 16 + NP + g) : (g * 16 + c);
+
+    // shared (time-invariant) cost Hessian: once, into registers
+    double Csh[KS], Cush = 0.0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) Csh[s] = 0.0;
+    if constexpr (SHARED) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const double t = c_xx[cA ? (4 * s + g) * N + c : 0];
+            Csh[s] = cA ? t : 0.0;
+        }
+        const double tu = cA ? c_ux[g * N + c] : (cB ? c_uu[g * M + (c - N)] : 0.0);
+        Cush = tu;
+    }
+    // terminal value function
+    double Vxx[KS], vxr[KS];
+    {
+        const double* vxx = SHARED ? vf_xx : vf_xx + traj * svxx;
+        const double* vx = vf_x + traj * svx;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int row = 4 * s + g;
+            const double t = vxx[cA ? row * N + c : 0];
+            Vxx[s] = cA ? t : 0.0;
+            vxr[s] = vx[row];
+        }
+        if (g == 0) sm[80 + c] = cA ? vx[c] : 0.0;
+    }
+    ilqr_lds_sync();
+
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+        if (T - 1 - i >= 0) dma(lds + i * SLOT);
+    int j = T - 1;
+    for (;;) {
+#pragma unroll
+        for (int si = 0; si < D; ++si) {
+            char* slot = lds + si * SLOT;
+            wait_for_step<NI, D>(j);
+            IlqrStepRegs<KS> d;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) d.F[s] = *(const double*)(slot + oF + s * dF);
+            d.cv = *(const double*)(slot + ocv);
+            if constexpr (SHARED) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) d.C[s] = Csh[s];
+                d.Cu = Cush;
+            } else {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) d.C[s] = *(const double*)(slot + oC + s * dC);
+                d.Cu = *(const double*)(slot + oCu);
+            }
+            if constexpr (MODE == 1) {
+                d.dc = *(const double*)(slot + odc);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) d.dr[s] = *(const double*)(slot + G::OD + (4 * s + g) * 8);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // operands are in registers: the slot may be refilled
+            if (j - D >= 0) dma(slot);
+            ilqr_step<KS, MODE, false>(Vxx, vxr, d, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, nullptr, nullptr, nullptr, nullptr, N, M);
+            if (--j < 0) return;
+        }
+    }
+}
+
+// ZM_EUNSUPPORTED unless (n in {8, 12}, m = 4, 16-B aligned pointers): the caller then runs the register-prefetch kernel
+template <int MODE>
+static int ilqr_backward_dma_dispatch(const double* f_x, const double* f_u, const double* c_x, const double* c_u,
+                                      const double* c_xx, const double* c_ux, const double* c_uu, const double* vf_x,
+                                      const double* vf_xx, const double* dvec, long svx, long svxx, const int* act, int sh,
+                                      double* l, double* L, int64_t batch, int T, int n, int m, hipStream_t st) {
+    static const bool off = [] {
+        const char* e = getenv("ZOPT_AMD_ILQR_PATH");
+        return e && e[0] == 'r';   // "reg": force the register-prefetch kernel
+    }();
+    if (off || m != 4 || (n != 8 && n != 12)) return ZM_EUNSUPPORTED;
+    const uintptr_t al = (uintptr_t)f_x | (uintptr_t)f_u | (uintptr_t)c_x | (uintptr_t)c_u | (uintptr_t)dvec |
+                         (sh ? 0 : ((uintptr_t)c_xx | (uintptr_t)c_ux | (uintptr_t)c_uu));
+    if (al & 15) return ZM_EUNSUPPORTED;
+    const dim3 grid((unsigned)batch), block(64);
+    // ring depth: 3 steps in flight when the step image is 2 KB (shared Hessians), 2 when it is 4 KB (measured: profiles/)
+    constexpr int DS = 3, DF = 2;
+#define ZM_LAUNCH_ILQR_DMA(NN, DD, SH)                                                                                     \
+    hipLaunchKernelGGL((ilqr_backward_dma_f64<NN, 4, DD, SH, MODE>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, \
+                       vf_x, vf_xx, dvec, svx, svxx, act, l, L, T)
+    if constexpr (MODE == 0) {
+        if (n == 12) {
+            if (sh) ZM_LAUNCH_ILQR_DMA(12, DS, true); else ZM_LAUNCH_ILQR_DMA(12, DF, false);
+        } else {
+            if (sh) ZM_LAUNCH_ILQR_DMA(8, DS, true); else ZM_LAUNCH_ILQR_DMA(8, DF, false);
+        }
+    } else {
+        if (n == 12) ZM_LAUNCH_ILQR_DMA(12, DF, false); else ZM_LAUNCH_ILQR_DMA(8, DF, false);
+    }
+#undef ZM_LAUNCH_ILQR_DMA
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+
+}  // namespace zm
+
 namespace zm {
 struct DdpTensors {
     const double *f_xx, *f_ux, *f_uu;
@@ -485,7 +701,10 @@ extern "C" int zm_ilqr_backward_ex_f64(const double* f_x, const double* f_u, con
         return zm::set_error(ZM_EINVAL, "zm_ilqr_backward_f64: null pointer");
     const int rc = zm_check_sweep_args("zm_ilqr_backward_f64", batch, T, n, m);
     if (rc) return rc;
-    if (batch == 0) return ZM_OK;
+    if (zm::ilqr_backward_dma_dispatch<0>(f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, (long)n, (long)n * n,
+                                       (const int*)active, shared_hessian ? 1 : 0, l, L, batch, T, n, m,
+                                       (hipStream_t)stream) == ZM_OK)
+        return ZM_OK;
     return zm::launch_ilqr<0>(f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, (long)n, (long)n * n,
                               (const int*)active, shared_hessian ? 1 : 0, l, L, batch, T, n, m, (hipStream_t)stream);
 }
@@ -511,6 +730,9 @@ extern "C" int zm_lqr_backward_affine_f64(const double* A, const double* B, cons
     // carry (V, v) <- (Q[T-1], q[T-1])   (lqrUtils.py:261): terminal pointers into the last step, trajectory stride T*size
     const double* vf_xx = Q + (int64_t)(T - 1) * n * n;
     const double* vf_x = q + (int64_t)(T - 1) * n;
+    if (zm::ilqr_backward_dma_dispatch<1>(A, B, q, r, Q, H, R, vf_x, vf_xx, d, (long)T * n, (long)T * n * n, nullptr, 0, l, L,
+                                          batch, T, n, m, (hipStream_t)stream) == ZM_OK)
+        return ZM_OK;
     return zm::launch_ilqr<1>(A, B, q, r, Q, H, R, vf_x, vf_xx, d, (long)T * n, (long)T * n * n, nullptr, 0, l, L, batch, T,
                               n, m, (hipStream_t)stream);
 }
