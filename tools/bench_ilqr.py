@@ -41,7 +41,7 @@ def main():
     t = min(times)
     print(json.dumps({"workload": f"{'differentialDynamicProgramming' if args.ddp else 'iterativeLqr'} quadcopter n=12 m=4 T={args.T} batch={args.batch} fp64",
                       "solve_ms": t * 1e3, "converged_frac": float(conv.double().mean().item()),
-                      "J_mean": float(J.mean().item()),
+                      "J_mean_finite": float(J[torch.isfinite(J)].mean().item()), "J_nonfinite_frac": float((~torch.isfinite(J)).double().mean().item()),
                       "trajectories_per_s": args.batch / t}))
 
 

@@ -234,17 +234,23 @@ __global__ __launch_bounds__(64, 4) void lqr_backward_dma_f64(const double* __re
 template <int N, int M>
 static int launch_dma(const double* A, const double* B, const double* Q, const double* R, double* L, int64_t batch,
                       int T, hipStream_t stream) {
-    constexpr int D = 3;
     // default: the [Sux | Suu] rows by v_mfma_f64_4x4x4_4b blocks (+2.6 % at steady state); ZOPT_AMD_LQR_G4=0 selects the three
     // full-tile MFMAs instead (A/B measurements)
     static const bool g4 = [] {
         const char* e = getenv("ZOPT_AMD_LQR_G4");
         return !(e && e[0] == '0');
     }();
-    if (g4)
-        hipLaunchKernelGGL((lqr_backward_dma_f64<N, M, D, true>), dim3((unsigned)batch), dim3(64), 0, stream, A, B, Q, R, L, T);
+    static const int depth = [] {   // ring depth (steps in flight per wave): 3 unless ZOPT_AMD_LQR_D=2 (A/B measurements)
+        const char* e = getenv("ZOPT_AMD_LQR_D");
+        return (e && e[0] == '2') ? 2 : 3;
+    }();
+    const dim3 grid((unsigned)batch), block(64);
+    if (!g4)
+        hipLaunchKernelGGL((lqr_backward_dma_f64<N, M, 3, false>), grid, block, 0, stream, A, B, Q, R, L, T);
+    else if (depth == 2)
+        hipLaunchKernelGGL((lqr_backward_dma_f64<N, M, 2, true>), grid, block, 0, stream, A, B, Q, R, L, T);
     else
-        hipLaunchKernelGGL((lqr_backward_dma_f64<N, M, D, false>), dim3((unsigned)batch), dim3(64), 0, stream, A, B, Q, R, L, T);
+        hipLaunchKernelGGL((lqr_backward_dma_f64<N, M, 3, true>), grid, block, 0, stream, A, B, Q, R, L, T);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }
