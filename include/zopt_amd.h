@@ -71,6 +71,31 @@ int zm_lqr_backward_affine_f64(const double* A, const double* B, const double* d
 int zm_dare_f64(const double* A, const double* B, const double* Q, const double* R, double* L, double* P, int32_t* iters,
                 int64_t batch, int n, int m, double tol, int max_iter, void* stream);
 
+/* Batched continuous-time infinite-horizon LQR (CARE  A^T P + P A - P B R^-1 B^T P + Q = 0) by the structure-preserving
+ * doubling algorithm, one wave per design.
+ * Replaces: zopt/lqrUtils.py:13-36 infiniteHorizonLqr (SciPy solve_continuous_are + one solve); with the integral-augmented
+ *           system of lqrUtils.py:101-141 also infiniteHorizonIntegralLqr.
+ * in : A (batch,n,n)  B (batch,n,m)  Q (batch,n,n)  R (batch,m,m)   [device]; n <= 16, m <= 16; Q, R symmetric
+ *      tol: stop when max|P' - P| <= tol * max|P'|; max_iter: cap on doubling steps (each squares the contraction: ~10 suffice)
+ * out: K (batch,m,n) = R^-1 B^T P with u = -K x;  P (batch,n,n) or NULL;
+ *      info (batch) or NULL: doubling steps taken, -1 not converged, -2 singular pivot / no stabilising solution
+ */
+int zm_care_f64(const double* A, const double* B, const double* Q, const double* R, double* K, double* P, int32_t* info,
+                int64_t batch, int n, int m, double tol, int max_iter, void* stream);
+
+/* Batched continuous-time finite-horizon LQR value function: dV/dt = -Q + V S V - V A - A^T V, V(T) = Qf, S = B R^-1 B^T,
+ * integrated backwards with an adaptive Dormand-Prince 5(4) pair, output at t_j = j T / (N - 1), j = 0..N-1.
+ * Replaces: zopt/lqrUtils.py:39-98 finiteHorizonLqr (_lqrHjb + jax.experimental.ode.odeint; its gain interpolation,
+ *           jaxUtils.py:7-24, stays on the host side of the boundary).
+ * in : A_s, Q_s (batch,n_samples,n,n), B_s (batch,n_samples,n,m), Rinv_s (batch,n_samples,m,m) [device]: coefficients sampled
+ *      at linspace(0, T, n_samples), linear in between (n_samples = 1: time-invariant);  Qf (batch,n,n);  n <= 16, m <= 16;
+ *      rtol, atol: local error control (odeint: 1.4e-8 both)
+ * out: V (batch,N,n,n);  info (batch) or NULL: integration steps taken, -1 step cap reached, -2 NaN (finite escape time)
+ */
+int zm_riccati_ode_f64(const double* A_s, const double* B_s, const double* Rinv_s, const double* Q_s, const double* Qf,
+                       double* V, int32_t* info, int64_t batch, int n, int m, int n_samples, int N, double T, double rtol,
+                       double atol, int max_steps, void* stream);
+
 /* fp32 batched finite-horizon LQR backward sweep for large states (n <= 64, m <= 16): fp32 MFMA tile kernel.
  * Replaces: zopt/lqrUtils.py:144-173 discreteFiniteHorizonLqr when JAX runs in its default fp32 mode (x64 disabled, quirk Q8);
  *           the "large-state stress" shape n=64, m=16, T=200 of BASELINE configs[4].

@@ -576,3 +576,53 @@ def discreteInfiniteHorizonLqr(A, B, Q, R):
     A, B, Q, R = (np.asarray(x, dtype=np.float64) for x in (A, B, Q, R))
     V = spl.solve_discrete_are(A, B, Q, R)
     return np.linalg.solve(R + B.T @ V @ B, B.T @ V @ A), V
+
+
+def infiniteHorizonLqr(A, B, Q, R):
+    """lqrUtils.py:34-36 verbatim in meaning: P = scipy.linalg.solve_continuous_are(A, B, Q, R); K = solve(R, B^T P).
+    SciPy is the library the reference itself calls."""
+    import scipy.linalg as spl
+    A, B, Q, R = (np.asarray(x, dtype=np.float64) for x in (A, B, Q, R))
+    P = spl.solve_continuous_are(A, B, Q, R)
+    return np.linalg.solve(R, B.T @ P), P
+
+
+def infiniteHorizonIntegralLqr(A, B, Q, R, Qi, Ci):
+    """lqrUtils.py:125-141: integral-augmented system [[0, Ci], [0, A]], [[0], [B]], blkdiag(Qi, Q) through infiniteHorizonLqr."""
+    import scipy.linalg as spl
+    A, B, Q, R, Qi, Ci = (np.asarray(x, dtype=np.float64) for x in (A, B, Q, R, Qi, Ci))
+    n_i = Qi.shape[0]
+    n_x, n_u = B.shape
+    Aw = np.block([[np.zeros((n_i, n_i)), Ci], [np.zeros((n_x, n_i)), A]])
+    Bw = np.vstack([np.zeros((n_i, n_u)), B])
+    Qw = spl.block_diag(Qi, Q)
+    K, _ = infiniteHorizonLqr(Aw, Bw, Qw, R)
+    return K[:, :n_i], K[:, n_i:]
+
+
+def lqrHjb(t, V, A, B, Q, R_inv, n):
+    """lqrUtils.py:39-52 (_lqrHjb): dV = -Q + V B R_inv B^T V - V A - A^T V, flattened."""
+    V = np.asarray(V, dtype=np.float64).reshape((n, n))
+    dV = -Q(t) + V @ B(t) @ R_inv(t) @ B(t).T @ V - V @ A(t) - A(t).T @ V
+    return dV.reshape(-1)
+
+
+def finiteHorizonLqr(A, B, Q, R_inv, Qf, T, N=50, rtol=1e-12, atol=1e-14):
+    """lqrUtils.py:85-97: integrate dV/ds = -lqrHjb(T - s, V) from V(0) = Qf over s in linspace(0, T, N), reverse, and
+    interpolate linearly (jaxUtils.py:7-24: jnp.interp per component, clipped at the ends).  The reference integrates with
+    jax.experimental.ode.odeint (Dormand-Prince 5(4), rtol = atol = 1.4e-8); jax is absent here, so this restatement
+    integrates the same ODE with SciPy's DOP853 at tight tolerances -- the two agree to the reference's own tolerance.
+    Returns (K, t, V) with K(t) = R_inv(t) @ B(t).T @ V(t), t (N,), V (N, n, n)."""
+    from scipy.integrate import solve_ivp
+    Qf = np.asarray(Qf, dtype=np.float64)
+    n = np.asarray(A(0)).shape[0]
+    t = np.linspace(0, T, num=N)
+    sol = solve_ivp(lambda s, V: -lqrHjb(T - s, V, A, B, Q, R_inv, n), (0.0, float(T)), Qf.reshape(-1), method="DOP853",
+                    t_eval=t, rtol=rtol, atol=atol)
+    assert sol.success
+    V = sol.y.T[::-1].reshape(N, n, n)          # V[j] is the value at time t[j]
+
+    def Vfun(tq):
+        return np.stack([np.interp(tq, t, V[:, i, j]) for i in range(n) for j in range(n)]).reshape(n, n)
+
+    return (lambda tq: R_inv(tq) @ B(tq).T @ Vfun(tq)), t, V

@@ -50,6 +50,12 @@ def test_bad_arguments_return_codes_without_gpu():
     assert rc == _lib.ZM_EUNSUPPORTED
     rc = lib.zm_lqr_backward_f64(dummy, dummy, dummy, dummy, dummy, -1, 5, 2, 2, None)
     assert rc == _lib.ZM_EINVAL
+    assert lib.zm_care_f64(dummy, dummy, dummy, dummy, dummy, None, None, 1, 17, 2, 1e-14, 60, None) == _lib.ZM_EUNSUPPORTED
+    assert lib.zm_care_f64(dummy, dummy, dummy, dummy, None, None, None, 1, 4, 2, 1e-14, 60, None) == _lib.ZM_EINVAL
+    assert lib.zm_riccati_ode_f64(dummy, dummy, dummy, dummy, dummy, dummy, None, 1, 4, 2, 1, 50, -1.0, 1e-8, 1e-8, 100,
+                                  None) == _lib.ZM_EINVAL
+    assert lib.zm_riccati_ode_f64(dummy, dummy, dummy, dummy, dummy, dummy, None, 1, 17, 2, 1, 50, 1.0, 1e-8, 1e-8, 100,
+                                  None) == _lib.ZM_EUNSUPPORTED
     with pytest.raises(ValueError):
         _lib.check(rc, "x")
 
@@ -63,6 +69,10 @@ def test_python_surface_mirrors_reference_signatures():
     assert params(lqrUtils.discreteFiniteHorizonLqr) == ["A", "B", "Q", "R", "N"]
     assert params(lqrUtils.discreteInfiniteHorizonLqr)[:4] == ["A", "B", "Q", "R"]
     assert params(lqrUtils.bilinearAffineLqr) == ["A", "B", "d", "Q", "R", "H", "q", "r", "q0", "N"]
+    assert params(lqrUtils.infiniteHorizonLqr)[:4] == ["A", "B", "Q", "R"]                              # lqrUtils.py:13
+    assert params(lqrUtils.infiniteHorizonIntegralLqr) == ["A", "B", "Q", "R", "Qi", "Ci"]              # lqrUtils.py:101
+    assert params(lqrUtils.finiteHorizonLqr)[:7] == ["A", "B", "Q", "R_inv", "Qf", "T", "N"]            # lqrUtils.py:55
+    assert inspect.signature(lqrUtils.finiteHorizonLqr).parameters["N"].default == 50
     assert params(lqrUtils.proportionalFeedbackController) == ["x", "x0", "u0", "K"]
     assert params(ilqrUtils.trajectoryRollout) == ["x0", "dynFun", "policy", "trajPrev", "alpha"]
     assert params(ilqrUtils.forwardPass2) == ["x0", "dynFun", "costFun", "policy", "trajPrev"]

@@ -231,3 +231,24 @@ def test_dare_oracle_known_answer():
     L, V = zo.discreteInfiniteHorizonLqr(I, I, I, I)
     assert L == pytest.approx((1 + np.sqrt(5)) / (3 + np.sqrt(5)) * np.eye(2))
     assert V == pytest.approx((1 + np.sqrt(5)) / 2 * np.eye(2))
+
+
+def test_continuous_lqr_oracle_known_answers():
+    """reference tests/test_lqrUtils.py:8-15 (K = (1 + sqrt 2) I), :18-28 (_lqrHjb), :31-44 (finiteHorizonLqr: K(T) = I and the
+    analytic scalar Riccati solution at t = 0), :47-58 (integral LQR: Ki = [[1],[0]], Kp = diag(3, 1 + sqrt 2))."""
+    K, P = zo.infiniteHorizonLqr(I2, I2, I2, I2)
+    assert K == pytest.approx((1 + np.sqrt(2)) * I2) and P == pytest.approx((1 + np.sqrt(2)) * I2)
+    k = KATS["CARE_infiniteHorizonIntegralLqr"]
+    Ki, Kp = zo.infiniteHorizonIntegralLqr(I2, I2, I2, I2, np.array(k["Qi"]), np.array(k["Ci"]))
+    assert Ki == pytest.approx(np.array(k["Ki"]), abs=1e-12)
+    assert Kp == pytest.approx(np.diag([3, 1 + np.sqrt(2)]))
+    c = lambda t: I2
+    assert zo.lqrHjb(KATS["ODE_lqrHjb"]["t"], I2, c, c, c, c, 2) == pytest.approx(np.array(KATS["ODE_lqrHjb"]["dV_flat"]))
+    f = KATS["ODE_finiteHorizonLqr"]
+    Kf, t, V = zo.finiteHorizonLqr(c, c, c, c, I2, f["T"], N=f["N"])
+    assert Kf(f["T"]) == pytest.approx(I2)
+    s2 = np.sqrt(2)
+    K_exp = lambda tq: ((1 + s2) * np.exp(2 * s2) - (s2 - 1) * np.exp(2 * s2 * tq)) / (np.exp(2 * s2 * tq) + np.exp(2 * s2))
+    assert Kf(0) == pytest.approx(K_exp(0) * I2, rel=f["K(0)_rel"])
+    assert Kf(0) == pytest.approx(K_exp(0) * I2, rel=1e-10)
+    assert V[1] == pytest.approx(K_exp(t[1]) * I2, rel=1e-10)

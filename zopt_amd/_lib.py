@@ -30,6 +30,10 @@ SYMBOLS = {
                                            ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "zm_dare_f64": (ctypes.c_int, [_c_dp] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int,
                                    ctypes.c_void_p]),
+    "zm_care_f64": (ctypes.c_int, [_c_dp] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                   ctypes.c_void_p]),
+    "zm_riccati_ode_f64": (ctypes.c_int, [_c_dp] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_void_p]),
     "zm_lqr_backward_host_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, ctypes.c_int64, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int]),
     "zm_lqr_backward_affine_f64": (ctypes.c_int, [_c_dp] * 10 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,

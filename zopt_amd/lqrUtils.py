@@ -135,6 +135,194 @@ def discreteInfiniteHorizonLqr(A, B, Q, R, tol=1e-14, maxIter=200000, return_val
     return arr.result_like(dL, A)
 
 
+def _check_symmetric(name, X):
+    """scipy.linalg.solve_continuous_are rejects nonsymmetric q / r with a ValueError (its _are_validate_args)."""
+    if X.numel() and float((X - X.transpose(-1, -2)).abs().max()) > 100 * np.finfo(np.float64).eps * max(float(X.abs().max()), 1.0):
+        _shape_error(f"Matrix {name} should be symmetric/hermitian.")
+
+
+def infiniteHorizonLqr(A, B, Q, R, tol=1e-14, maxIter=60, return_value=False):
+    """Continuous-time infinite-horizon LQR gains (reference lqrUtils.py:13-36: SciPy `solve_continuous_are` + one solve).
+
+    ```
+    J = int_t(x^T Q x + u^T R u);   xDot = A x + B u;   uLqr = -K x
+    ```
+    Here: the stabilising solution of the algebraic Riccati equation by the structure-preserving doubling algorithm on the GPU,
+    one wave per design (quadratically convergent: ~10 doubling steps), `K = R^-1 B^T P`.
+
+    Arguments
+    ---------
+        A : (..., n, n)    B : (..., n, m)    Q : (..., n, n)    R : (..., m, m)     (n <= 16, m <= 16; Q, R symmetric)
+
+    Returns
+    -------
+        K : (..., m, n) LQR gains   (with `return_value=True`: (K, P, doubling steps))
+    """
+    shp = tuple(B.shape) if hasattr(B, "shape") else tuple(np.shape(B))
+    if len(shp) < 2:
+        _shape_error("B must have shape (..., n, m)")
+    n, m = shp[-2:]
+    lead = shp[:-2]
+    for name, X, tail in (("A", A, (n, n)), ("B", B, (n, m)), ("Q", Q, (n, n)), ("R", R, (m, m))):
+        s_ = tuple(X.shape) if hasattr(X, "shape") else tuple(np.shape(X))
+        if s_ != lead + tail:
+            _shape_error(f"{name} has shape {s_}, expected {lead + tail}")
+    dt = torch.float64
+    dA, dB, dQ, dR = [arr.to_device(X, dt) for X in (A, B, Q, R)]
+    _check_symmetric("q", dQ)
+    _check_symmetric("r", dR)
+    batch = 1
+    for d in lead:
+        batch *= int(d)
+    dK = torch.empty(lead + (m, n), dtype=dt, device=dA.device)
+    dP = torch.empty(lead + (n, n), dtype=dt, device=dA.device)
+    info = torch.ones(lead, dtype=torch.int32, device=dA.device)
+    rc = 0 if batch == 0 else _lib.lib().zm_care_f64(dA.data_ptr(), dB.data_ptr(), dQ.data_ptr(), dR.data_ptr(), dK.data_ptr(),
+                                                     dP.data_ptr(), info.data_ptr(), batch, n, m, float(tol), int(maxIter),
+                                                     ctypes.c_void_p(arr.stream_ptr(dA)))
+    _lib.check(rc, "infiniteHorizonLqr")
+    if batch and int(info.min()) < 0:    # SciPy: LinAlgError('Failed to find a finite solution.')
+        raise np.linalg.LinAlgError("infiniteHorizonLqr: failed to find a finite stabilising solution "
+                                    f"({int((info < 0).sum())} of {batch} designs)")
+    fp32_in = (arr.is_torch(A) and A.dtype == torch.float32) or (not arr.is_torch(A) and np.asarray(A).dtype == np.float32)
+    if fp32_in:
+        dK, dP = dK.to(torch.float32), dP.to(torch.float32)
+    if return_value:
+        return arr.result_like(dK, A), arr.result_like(dP, A), arr.result_like(info, A)
+    return arr.result_like(dK, A)
+
+
+def infiniteHorizonIntegralLqr(A, B, Q, R, Qi, Ci):
+    """Infinite-horizon LQR with integral states (reference lqrUtils.py:101-141).
+
+    ```
+    J = int_t(z^T Q_i z + x^T Q x + u^T R u);   zDot = C_i x;   xDot = A x + B u
+    ```
+    The integral-augmented system `[[0, Ci], [0, A]]`, `[[0], [B]]`, `blkdiag(Qi, Q)` (:129-132) goes through `infiniteHorizonLqr`.
+
+    Arguments
+    ---------
+        A : (..., n, n)   B : (..., n, m)   Q : (..., n, n)   R : (..., m, m)   Qi : (..., ni, ni)
+        Ci : (..., ni, n)  -- or (..., n) for a single integral state, as the reference's own test passes it     (ni + n <= 16)
+
+    Returns
+    -------
+        Ki : (..., m, ni) integral gains      Kp : (..., m, n) proportional gains
+    """
+    dt = torch.float64
+    dA, dB, dQ, dR, dQi, dCi = [arr.to_device(X, dt) for X in (A, B, Q, R, Qi, Ci)]
+    if dB.dim() < 2 or dQi.dim() < 2:
+        _shape_error("B must have shape (..., n, m) and Qi (..., ni, ni)")
+    n, m = dB.shape[-2:]
+    ni = dQi.shape[-1]
+    lead = tuple(dB.shape[:-2])
+    if dCi.dim() == len(lead) + 1:       # np.block promotes a 1-D Ci to one row (:129)
+        dCi = dCi.unsqueeze(-2)
+    for name, X, tail in (("A", dA, (n, n)), ("Q", dQ, (n, n)), ("R", dR, (m, m)), ("Qi", dQi, (ni, ni)), ("Ci", dCi, (ni, n))):
+        if tuple(X.shape) != lead + tail:
+            _shape_error(f"{name} has shape {tuple(X.shape)}, expected {lead + tail}")
+    z = lambda r, c: torch.zeros(lead + (r, c), dtype=dt, device=dA.device)
+    Aw = torch.cat([torch.cat([z(ni, ni), dCi], -1), torch.cat([z(n, ni), dA], -1)], -2)
+    Bw = torch.cat([z(ni, m), dB], -2)
+    Qw = torch.cat([torch.cat([dQi, z(ni, n)], -1), torch.cat([z(n, ni), dQ], -1)], -2)
+    K = infiniteHorizonLqr(Aw.contiguous(), Bw.contiguous(), Qw.contiguous(), dR)
+    return arr.result_like(K[..., :, :ni].contiguous(), A), arr.result_like(K[..., :, ni:].contiguous(), A)
+
+
+class _GainSchedule:
+    """`K(t) = R_inv(t) @ B(t).T @ V(t)` with V linearly interpolated between the N grid values, clipped at the ends
+    (reference lqrUtils.py:94-97, jaxUtils.py:7-24).  `t`, `V` hold the grid (N,) and the value function (..., N, n, n)."""
+
+    def __init__(self, t, V, B, R_inv, T):
+        self.t, self.V, self._B, self._Ri, self._T = t, V, B, R_inv, float(T)
+
+    def value(self, tq):
+        N = self.V.shape[-3]
+        if N == 1:
+            return self.V[..., 0, :, :]
+        u = min(max(float(tq) / self._T, 0.0), 1.0) * (N - 1)
+        i0 = min(int(u), N - 2)
+        w = u - i0
+        return self.V[..., i0, :, :] + w * (self.V[..., i0 + 1, :, :] - self.V[..., i0, :, :])
+
+    def __call__(self, tq):
+        B, Ri = self._B(tq), self._Ri(tq)
+        V = self.value(tq)
+        if arr.is_torch(V):
+            B, Ri = arr.to_device(B, V.dtype, V.device), arr.to_device(Ri, V.dtype, V.device)
+            return Ri @ B.transpose(-1, -2) @ V
+        return np.asarray(Ri) @ np.swapaxes(np.asarray(B), -1, -2) @ V
+
+
+def finiteHorizonLqr(A, B, Q, R_inv, Qf, T, N=50, n_samples=None, rtol=1.4e-8, atol=1.4e-8, max_steps=100000):
+    """Continuous-time finite-horizon LQR gains by integrating the LQR Hamilton-Jacobi-Bellman (Riccati) equation
+    (reference lqrUtils.py:39-98).
+
+    ```
+    J = xf^T Qf xf + int_t(x^T Q x + u^T R u);   xDot = A x + B u;   uLqr = -K(t) x
+    ```
+    Here: `dV/dt = -Q + V B R_inv B^T V - V A - A^T V` backwards from `V(T) = Qf` on the GPU, one wave per design, with the
+    adaptive Dormand-Prince 5(4) pair and tolerances of `jax.experimental.ode.odeint` (the reference's integrator), stepping
+    exactly onto the output times `linspace(0, T, N)`.  The coefficient callables are host Python: they are sampled at
+    `linspace(0, T, n_samples)` (default `8 (N - 1) + 1`; a single sample when all samples agree) and the kernel interpolates
+    linearly in between -- exact for time-invariant (the reference's demos and tests) and piecewise-linear coefficients.
+
+    Arguments
+    ---------
+        A, B, Q, R_inv : callables of time returning (..., n, n), (..., n, m), (..., n, n), (..., m, m)      (n <= 16, m <= 16)
+        Qf : (..., n, n) terminal state cost matrix
+        T : time horizon;  N : number of output times
+
+    Returns
+    -------
+        K : callable `K(t)` -> (..., m, n);  `K.t` (N,) and `K.V` (..., N, n, n) expose the integrated value function
+    """
+    T = float(T)
+    N = int(N)
+    if not (T > 0.0) or N < 1:
+        _shape_error("T must be > 0 and N >= 1")
+    ns = int(n_samples) if n_samples is not None else 8 * (N - 1) + 1
+    if ns < 1:
+        _shape_error("n_samples must be >= 1")
+    dt = torch.float64
+    ts = np.linspace(0.0, T, ns)
+    dev = arr.to_device(Qf, dt).device
+
+    def sample(f):
+        vals = [arr.to_device(f(float(tk)), dt, dev) for tk in ts]
+        if all(v.shape == vals[0].shape and bool((v == vals[0]).all()) for v in vals[1:]):
+            vals = vals[:1]           # time-invariant
+        return vals
+
+    sA, sB, sQ, sRi = sample(A), sample(B), sample(Q), sample(R_inv)
+    cnt = max(len(sA), len(sB), len(sQ), len(sRi))
+    stack = lambda v: torch.stack(v if len(v) == cnt else v * cnt, dim=-3).contiguous()
+    dA, dB, dQ, dRi = stack(sA), stack(sB), stack(sQ), stack(sRi)
+    dQf = arr.to_device(Qf, dt, dev).contiguous()
+    if dB.dim() < 3:
+        _shape_error("B(t) must have shape (..., n, m)")
+    n, m = dB.shape[-2:]
+    lead = tuple(dB.shape[:-3])
+    for name, X, tail in (("A(t)", dA, (cnt, n, n)), ("Q(t)", dQ, (cnt, n, n)), ("R_inv(t)", dRi, (cnt, m, m))):
+        if tuple(X.shape) != lead + tail:
+            _shape_error(f"{name} has shape {tuple(X.shape[:-3]) + tuple(X.shape[-2:])}, expected {lead + tail[1:]}")
+    if tuple(dQf.shape) != lead + (n, n):
+        _shape_error(f"Qf has shape {tuple(dQf.shape)}, expected {lead + (n, n)}")
+    batch = 1
+    for d in lead:
+        batch *= int(d)
+    dV = torch.empty(lead + (N, n, n), dtype=dt, device=dev)
+    info = torch.ones(lead, dtype=torch.int32, device=dev)
+    rc = 0 if batch == 0 else _lib.lib().zm_riccati_ode_f64(dA.data_ptr(), dB.data_ptr(), dRi.data_ptr(), dQ.data_ptr(),
+                                                            dQf.data_ptr(), dV.data_ptr(), info.data_ptr(), batch, n, m, cnt, N,
+                                                            T, float(rtol), float(atol), int(max_steps),
+                                                            ctypes.c_void_p(arr.stream_ptr(dQf)))
+    _lib.check(rc, "finiteHorizonLqr")
+    K = _GainSchedule(np.linspace(0.0, T, N), arr.result_like(dV, Qf), B, R_inv, T)
+    K.info = arr.result_like(info, Qf)
+    return K
+
+
 def bilinearAffineLqr(A, B, d, Q, R, H, q, r, q0, N):
     """Finite Horizon LQR with bilinear cost and affine dynamics (reference lqrUtils.py:207-262).
 
