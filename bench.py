@@ -192,6 +192,13 @@ def main():
                          "kernel": "lqr_backward_dma_f64<12,4,3>" if (n, m) == (12, 4) else "lqr_backward", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": bps * steps_per_launch},
         }
+        if (n, m) == (12, 4):
+            # Informational: the fp64 matrix pipe is the resource this kernel actually saturates.  Per horizon step the wave
+            # issues 9 v_mfma_f64_16x16x4 (2048 flop) + 3 v_mfma_f64_4x4x4_4b (512 flop); the sustained fp64 MFMA rate of the
+            # chip, measured at steady state (profiles/r01_ubench_mfma_f64_steady.txt), is 47.2 TFLOP/s (nominal 78.6).
+            issued = (9 * 2048 + 3 * 512) * steps_per_launch / (kern_ms * 1e-3) / 1e12
+            res["fp64_matrix_pipe"] = {"issued_mfma_tflops": issued, "sustained_peak_tflops": 47.2, "nominal_peak_tflops": 78.6,
+                                       "frac_of_sustained": issued / 47.2}
         if gather_ms is not None:
             res["allgather_ms"] = gather_ms
         if world == 1 and not args.no_cpu_baseline:

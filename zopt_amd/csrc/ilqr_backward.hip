@@ -37,6 +37,7 @@
 // nonsymmetric V is treated exactly as the reference does.
 #include "dma_ring.h"
 #include "jacobi16.h"
+#include "ns16.h"
 #include "tile16_f64.h"
 #include "zm_common.h"
 
@@ -65,6 +66,7 @@ struct IlqrAddr {
     const double* pz[4]; // MODE 2: element (4r+g, c) of the stacked second-derivative tensor slice i = 0; +i*sz[r]
     int sz[4], stz[4];   // MODE 2: stride over i, stride over the time step
     int zc[4];           // MODE 2: compact LDS index a*PLD+b of tile element (4r+g, c), or -1
+    bool zlive[4];       // MODE 2: tile element (4r+g, c) is a diagonal entry of the live (state, control) index set
     double* pOut;        // L_k[g][c] (c < n) or l_k[g] (c == NP)
     int dF, dC, sF, sC, sCu, scv, sOut, sd;
     bool rowok[KS], vF[KS], vC[KS], vCu, vcv, vOut, vL, cA;
@@ -145,6 +147,18 @@ __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], 
                 for (int r = 0; r < 4; ++r) z[r] = __builtin_fma(vxi, fz[i][r], z[r]);
             }
         }
+#ifndef ZM_DDP_PSD_JACOBI
+        // PD projection on the tile itself by matrix-sign iterations on the fp64 MFMA pipe (ns16.h); jA: transpose buffers
+        d4 zt;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a.pz[r] -= a.stz[r];
+            zt[r] = (a.zc[r] >= 0) ? z[r] : 0.0;   // padding lanes contracted don't-care data
+        }
+        psd_project_ns<KS + 1>(zt, a.zlive, 1e-3, jA, g, c);
+        pz = zt;
+        (void)lane;
+#else
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             a.pz[r] -= a.stz[r];
@@ -171,6 +185,7 @@ __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], 
         a.warm_v = true;   // jV now holds eigenvectors of a neighbouring step's matrix
 #pragma unroll
         for (int r = 0; r < 4; ++r) pz[r] = (a.zc[r] >= 0) ? jA[a.zc[r]] : 0.0;
+#endif
     }
     // Y = v_xx^T F
     d4 y = zero4();
@@ -293,7 +308,11 @@ __global__ __launch_bounds__(64, 2) void ilqr_backward_t16_f64(
     if (active && active[traj] == 0) return;  // whole wave leaves: this trajectory keeps its previous policy
     const int g = lane >> 4, c = lane & 15;
     __shared__ double sm[ILQR_LDS_DOUBLES];
+#ifndef ZM_DDP_PSD_JACOBI
+    __shared__ double jA[MODE == 2 ? NS_LDS_DOUBLES : 1], jV[1], jcs[1];
+#else
     __shared__ double jA[MODE == 2 ? PK * PLD : 1], jV[MODE == 2 ? PK * PLD : 1], jcs[PK];
+#endif
     __shared__ int jpq[PK];
 
     IlqrAddr<KS> a;
@@ -353,6 +372,7 @@ __global__ __launch_bounds__(64, 2) void ilqr_backward_t16_f64(
             const int ca = rx ? row : (ru ? n + (row - NP) : -1);
             const int cb = cA ? c : (cB ? n + (c - NP) : -1);
             a.zc[r] = (ca >= 0 && cb >= 0) ? ca * PLD + cb : -1;
+            a.zlive[r] = (ca >= 0) && (row == c);
             if (rx && cA) {            // f_xx[i][row][c]
                 a.pz[r] = fxxt + row * n + c;  a.sz[r] = nn;  a.stz[r] = (int)nnn;
             } else if (rx && cB) {     // (vf_ux)^T: f_ux[i][c-NP][row]
@@ -400,6 +420,14 @@ __global__ __launch_bounds__(64, 2) void ilqr_backward_t16_f64(
 
     if (g == 0) sm[80 + c] = cA ? (vf_x + traj * svx)[c] : 0.0;  // v_x (column-indexed), read by MODE 2's contraction
     ilqr_lds_sync();
+    if constexpr (MODE == 2) {
+        // a DDP step is ~100 matrix products long: operand prefetch buys nothing and its registers are needed elsewhere
+        for (int k2 = T - 1; k2 >= 0; --k2) {
+            IlqrStepRegs<KS> d;
+            ilqr_load_step<KS, MODE>(d, a);
+            ilqr_step<KS, MODE, false>(Vxx, vxr, d, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, jA, jV, jcs, jpq, n, m);
+        }
+    } else {
     IlqrStepRegs<KS> d0, d1;
     ilqr_load_step<KS, MODE>(d0, a);
     if (T >= 2) ilqr_load_step<KS, MODE>(d1, a);
@@ -418,6 +446,7 @@ __global__ __launch_bounds__(64, 2) void ilqr_backward_t16_f64(
         ilqr_step<KS, MODE, false>(Vxx, vxr, d1, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, jA, jV, jcs, jpq, n, m);
     } else {
         ilqr_step<KS, MODE, false>(Vxx, vxr, d0, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, jA, jV, jcs, jpq, n, m);
+    }
     }
     // optional: the value function the sweep ends with (riccatiStep_ilqr / _ddp return it: ilqrUtils.py:170, :203)
     if (vxx_out) {

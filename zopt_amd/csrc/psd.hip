@@ -11,6 +11,7 @@
 // Sweeps stop when a whole sweep found every |a_pq| <= 2^-52 * sqrt(|a_pp a_qq|) (quadratic convergence: one extra
 // sweep at most), or after 20 sweeps.
 #include "jacobi16.h"
+#include "ns16.h"
 #include "zm_common.h"
 
 namespace zm {
@@ -79,6 +80,40 @@ struct ContractedDynamics {
     }
 };
 
+#ifndef ZM_PSD_JACOBI
+// one wave per matrix: the k x k matrix sits zero-padded in one 16 x 16 MFMA tile (lane (g, c) holds rows 4r+g of column c) and
+// is projected by the matrix-sign iteration of ns16.h -- ~100-200 fp64 MFMAs instead of ~10 Jacobi sweeps through LDS
+template <class Mat, int KSZ>
+__device__ __forceinline__ void psd_project_tile(const Mat& M, const long mat, const int k, const double eps, double* T) {
+    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    d4 a;
+    bool live[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * r + g;
+        const bool in = (i < k) && (c < k);
+        a[r] = in ? M.load(mat, in ? i : 0, in ? c : 0) : 0.0;
+        live[r] = in && (i == c);
+    }
+    psd_project_ns<KSZ>(a, live, eps, T, g, c);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * r + g;
+        if (i < k && c < k) M.store(mat, i, c, a[r]);
+    }
+}
+
+template <class Mat>
+__global__ __launch_bounds__(64) void psd_project_kernel(const Mat M, const int k, const double eps, const long count) {
+    __shared__ double T[NS_LDS_DOUBLES];
+    const long mat = blockIdx.x;
+    if (mat >= count) return;
+    if (k <= 4) psd_project_tile<Mat, 1>(M, mat, k, eps, T);
+    else if (k <= 8) psd_project_tile<Mat, 2>(M, mat, k, eps, T);
+    else if (k <= 12) psd_project_tile<Mat, 3>(M, mat, k, eps, T);
+    else psd_project_tile<Mat, 4>(M, mat, k, eps, T);
+}
+#else
 template <class Mat>
 __global__ __launch_bounds__(64) void psd_project_kernel(const Mat M, const int k, const double eps, const long count) {
     __shared__ double As[PK * PLD], Vs[PK * PLD], cs[PK];
@@ -95,6 +130,8 @@ __global__ __launch_bounds__(64) void psd_project_kernel(const Mat M, const int 
     psd_project_lds(As, Vs, cs, pq, k, eps, lane);
     for (int e = lane; e < k * k; e += 64) M.store(mat, e / k, e % k, As[(e / k) * PLD + (e % k)]);
 }
+
+#endif
 
 }  // namespace zm
 
