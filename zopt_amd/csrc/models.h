@@ -11,6 +11,7 @@
 // The dynamics are templated on the scalar type so that the same code evaluated on dual numbers gives the
 // Jacobians (linearize kernel), as jax.jacobian does for the reference (pytrees.py:139-153).
 #pragma once
+#include "trig.h"
 #include <hip/hip_runtime.h>
 
 #include "../../include/zopt_amd.h"
@@ -43,15 +44,18 @@ __device__ __forceinline__ Dual operator/(double a, Dual b) {
     const double q = a / b.v;
     return {q, -q * b.d / b.v};
 }
-__device__ __forceinline__ Dual zsin(Dual a) { return {sin(a.v), cos(a.v) * a.d}; }
-__device__ __forceinline__ Dual zcos(Dual a) { return {cos(a.v), -sin(a.v) * a.d}; }
+// sin, cos and tan = sin / cos all come from one zm_sincos (trig.h); after inlining the compiler keeps a single evaluation per angle
+__device__ __forceinline__ Dual zsin(Dual a) { double s_, c_; zm_sincos(a.v, &s_, &c_); return {s_, c_ * a.d}; }
+__device__ __forceinline__ Dual zcos(Dual a) { double s_, c_; zm_sincos(a.v, &s_, &c_); return {c_, -s_ * a.d}; }
 __device__ __forceinline__ Dual ztan(Dual a) {
-    const double t = tan(a.v);
+    double s_, c_;
+    zm_sincos(a.v, &s_, &c_);
+    const double t = s_ / c_;
     return {t, (1.0 + t * t) * a.d};
 }
-__device__ __forceinline__ double zsin(double a) { return sin(a); }
-__device__ __forceinline__ double zcos(double a) { return cos(a); }
-__device__ __forceinline__ double ztan(double a) { return tan(a); }
+__device__ __forceinline__ double zsin(double a) { double s_, c_; zm_sincos(a, &s_, &c_); return s_; }
+__device__ __forceinline__ double zcos(double a) { double s_, c_; zm_sincos(a, &s_, &c_); return c_; }
+__device__ __forceinline__ double ztan(double a) { double s_, c_; zm_sincos(a, &s_, &c_); return s_ / c_; }
 
 // ---- hyper-dual number: value, two first-order parts and the mixed second-order part; f(x + e_a eps1 + e_b eps2)
 //      carries d2 f / dz_a dz_b in .d12 exactly (no truncation error) -- the role of jax.hessian (pytrees.py:180-186)
@@ -81,10 +85,12 @@ __device__ __forceinline__ Hyper operator*(Hyper a, double b) { return {a.v * b,
 __device__ __forceinline__ Hyper operator*(double a, Hyper b) { return {a * b.v, a * b.d1, a * b.d2, a * b.d12}; }
 __device__ __forceinline__ Hyper operator/(Hyper a, double b) { return {a.v / b, a.d1 / b, a.d2 / b, a.d12 / b}; }
 __device__ __forceinline__ Hyper operator/(double a, Hyper b) { return a * hyper_inv(b); }
-__device__ __forceinline__ Hyper zsin(Hyper a) { const double s_ = sin(a.v), c_ = cos(a.v); return hyper_fn(a, s_, c_, -s_); }
-__device__ __forceinline__ Hyper zcos(Hyper a) { const double s_ = sin(a.v), c_ = cos(a.v); return hyper_fn(a, c_, -s_, -c_); }
+__device__ __forceinline__ Hyper zsin(Hyper a) { double s_, c_; zm_sincos(a.v, &s_, &c_); return hyper_fn(a, s_, c_, -s_); }
+__device__ __forceinline__ Hyper zcos(Hyper a) { double s_, c_; zm_sincos(a.v, &s_, &c_); return hyper_fn(a, c_, -s_, -c_); }
 __device__ __forceinline__ Hyper ztan(Hyper a) {
-    const double t = tan(a.v), q = 1.0 + t * t;
+    double s_, c_;
+    zm_sincos(a.v, &s_, &c_);
+    const double t = s_ / c_, q = 1.0 + t * t;
     return hyper_fn(a, t, q, 2.0 * t * q);
 }
 

@@ -47,9 +47,9 @@ __device__ __forceinline__ void fast_step(const double* As, const double* Bs, co
         // quad_inertial_dynamics<double> with sincos (tan = sin/cos): models.h / quadcopter.py:23-144
         constexpr double g = 9.807, mass = 2.5;
         double sphi, cphi, sth, cth, spsi, cpsi;
-        sincos(x[6], &sphi, &cphi);
-        sincos(x[7], &sth, &cth);
-        sincos(x[8], &spsi, &cpsi);
+        zm_sincos(x[6], &sphi, &cphi);
+        zm_sincos(x[7], &sth, &cth);
+        zm_sincos(x[8], &spsi, &cpsi);
         const double tth = sth / cth;
         const double fa0 = -0.2 * x[0] + -0.05 * (x[0] * x[0]);
         const double fa1 = -0.2 * x[1] + -0.05 * (x[1] * x[1]);
