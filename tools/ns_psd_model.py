@@ -21,7 +21,11 @@ def ns_projection(A, k, eps=1e-3, stats=None):
     sym = lambda M: 0.5 * (M + M.T)
     I = np.zeros((16, 16))
     I[:k, :k] = np.eye(k)
-    X = sym(A) - eps * I
+    A = sym(A)
+    # indices with an exactly zero row/column: eigenvalue 0, decoupled -- they get eps on the diagonal and stay out of the iteration
+    Ir = I * (np.abs(A).sum(0) != 0)[None, :]
+    I_full, I = I, Ir
+    X = A - eps * I
     s = np.linalg.norm(X)
     Z = X / s if s > 0 else X
     pairs = cubic = mfma = 0
@@ -44,7 +48,7 @@ def ns_projection(A, k, eps=1e-3, stats=None):
                 break
     if stats is not None:
         stats.append((pairs, cubic, mfma + 4))
-    return sym(eps * I + 0.5 * (X + Z.T @ X))
+    return sym(eps * I_full + 0.5 * (X + Z.T @ X))
 
 
 def spectrum(kind, k, rng):
@@ -54,7 +58,7 @@ def spectrum(kind, k, rng):
         return np.concatenate([rng.standard_normal(k // 2), 1e-3 + rng.standard_normal(k - k // 2) * 1e-9])
     if kind == 2:   # 16 decades of magnitude, random signs
         return 10.0 ** rng.uniform(-14, 2, k) * rng.choice([-1, 1], k)
-    if kind == 3:   # rank one
+    if kind == 3:   # rank one (after rotation: dense, eigenvalue 0 with multiplicity k - 1)
         lam = np.zeros(k)
         lam[0] = rng.standard_normal()
         return lam

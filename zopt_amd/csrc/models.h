@@ -158,6 +158,15 @@ __device__ __forceinline__ void quad_inertial_dynamics(const S (&x)[12], const S
 }
 
 // One discrete step x+ = f(x, u) of a registered model.  n, m are the model's dimensions (<= MAXN, MAXM).
+// Variables (bit i: state i; bit n + j: control j) in which the model is NOT affine: only pairs of these can have a nonzero
+// second derivative.  The quadcopter's controls enter linearly (thrust along body z and the three moments, quadcopter.py:94-105)
+// and its inertial position does not enter at all; a linear model has no such variable.
+__device__ __forceinline__ unsigned model_nonlinear_mask(const zm_model_t& md) {
+    if (md.kind == ZM_MODEL_QUADCOPTER) return 0x1FFu;      // u v w p q r phi theta psi
+    if (md.kind == ZM_MODEL_QUADCOPTER_RB) return 0xFFu;    // u v w p q r phi theta
+    return 0u;
+}
+
 template <typename S>
 __device__ __forceinline__ void model_step(const zm_model_t& md, const S (&x)[MAXN], const S (&u)[MAXM], S (&xn)[MAXN]) {
     if (md.kind == ZM_MODEL_QUADCOPTER) {

@@ -88,8 +88,18 @@ __device__ __forceinline__ void psd_project_ns(d4& a, const bool (&live)[4], con
 #pragma unroll
     for (int r = 0; r < 4; ++r) id[r] = live[r] ? 1.0 : 0.0;
     a = ns_symmetrise(a, T, flip, g, c);        // jnp.linalg.eigh symmetrises its input
+    // An index whose row and column are exactly zero is an eigenvector with eigenvalue 0, decoupled from the rest: its projection
+    // is eps on the diagonal, and it stays out of the iteration (idr).  Otherwise X would carry the eigenvalue -eps once per such
+    // index -- 1e-4..1e-5 of |X| for the Hessians of a model that is affine in some of its variables -- and the sign iteration
+    // needs ~log(|X| / eps) booster steps to resolve it.
+    const bool nzl = (a[0] != 0.0) | (a[1] != 0.0) | (a[2] != 0.0) | (a[3] != 0.0);
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(nzl);
+    const bool colnz = ((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) >> c) & 1ull;
+    d4 idr;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) x[r] = a[r] - eps * id[r];
+    for (int r = 0; r < 4; ++r) idr[r] = (live[r] && colnz) ? 1.0 : 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = a[r] - eps * idr[r];
     double ss = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) ss = __builtin_fma(x[r], x[r], ss);
@@ -105,7 +115,7 @@ __device__ __forceinline__ void psd_project_ns(d4& a, const bool (&live)[4], con
             double f = 0.0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double e = id[r] - z2[r];
+                const double e = idr[r] - z2[r];
                 f = __builtin_fma(e, e, f);
             }
             f = ns_wave_sum(f);
@@ -113,17 +123,17 @@ __device__ __forceinline__ void psd_project_ns(d4& a, const bool (&live)[4], con
                 const d4 z4 = ns_op<KSZ>(z2, z2);
                 d4 w;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) w[r] = __builtin_fma(QC, z4[r], __builtin_fma(QB, z2[r], QA * id[r]));
+                for (int r = 0; r < 4; ++r) w[r] = __builtin_fma(QC, z4[r], __builtin_fma(QB, z2[r], QA * idr[r]));
                 z = ns_symmetrise(ns_op<KSZ>(z, w), T, flip, g, c);
                 z2 = ns_op<KSZ>(z, z);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) w[r] = 1.5 * id[r] - 0.5 * z2[r];
+                for (int r = 0; r < 4; ++r) w[r] = 1.5 * idr[r] - 0.5 * z2[r];
                 z = ns_symmetrise(ns_op<KSZ>(z, w), T, flip, g, c);
                 ++pairs;
             } else {
                 d4 w;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) w[r] = 1.5 * id[r] - 0.5 * z2[r];
+                for (int r = 0; r < 4; ++r) w[r] = 1.5 * idr[r] - 0.5 * z2[r];
                 z = ns_symmetrise(ns_op<KSZ>(z, w), T, flip, g, c);
                 ++cubic;
                 if (f < 1e-16 || cubic >= MAX_CUBIC) break;
