@@ -20,4 +20,6 @@ run ilqr      $R/tools/bench_ilqr.py --reps 1
 run mpc       $R/tools/bench_mpc.py --eps 1e-2
 run tiled     $R/tools/bench_lqr_tiled.py --batch 2048 --reps 2
 run sweeps    $R/tools/bench_ilqr_backward.py --reps 3
-grep -h "metric\|workload\|kernel" $OUT/*.log | cut -c1-400 > $OUT/results.jsonl
+run ddp       $R/tools/bench_ilqr.py --ddp --reps 1
+run psd       $R/tools/bench_psd.py
+grep -h "metric\|workload\|kernel\|count" $OUT/*.log | cut -c1-400 > $OUT/results.jsonl
