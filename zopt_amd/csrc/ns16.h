@@ -77,12 +77,48 @@ __device__ __forceinline__ d4 ns_symmetrise(const d4& v, double* T, int& flip, c
     return o;
 }
 
+// sign iteration on Z (scaled X) over K row groups; returns |X| = sign(X) X
+template <int K>
+__device__ __forceinline__ d4 ns_sign_times(d4 z, const d4& x, const d4& idr, double* T, int& flip, const int g, const int c) {
+    constexpr double QA = 3.4445, QB = -4.7750, QC = 2.0315;
+    constexpr int MAX_PAIRS = 18, MAX_CUBIC = 12;
+    int pairs = 0, cubic = 0;
+    for (;;) {
+        d4 z2 = ns_op<K>(z, z);
+        double f = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double e = idr[r] - z2[r];
+            f = __builtin_fma(e, e, f);
+        }
+        f = ns_wave_sum(f);
+        d4 w;
+        if (f > 0.9 && pairs < MAX_PAIRS) {
+            const d4 z4 = ns_op<K>(z2, z2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = __builtin_fma(QC, z4[r], __builtin_fma(QB, z2[r], QA * idr[r]));
+            z = ns_symmetrise(ns_op<K>(z, w), T, flip, g, c);
+            z2 = ns_op<K>(z, z);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = 1.5 * idr[r] - 0.5 * z2[r];
+            z = ns_symmetrise(ns_op<K>(z, w), T, flip, g, c);
+            ++pairs;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = 1.5 * idr[r] - 0.5 * z2[r];
+            z = ns_symmetrise(ns_op<K>(z, w), T, flip, g, c);
+            ++cubic;
+            if (f < 1e-16 || cubic >= MAX_CUBIC) break;
+        }
+    }
+    return ns_op<K>(z, x);
+}
+
 // a (D layout: a[r] = A[4r+g][c]) is replaced by its projection.  T: NS_LDS_DOUBLES of LDS private to the wave.
+// KSZ: row groups that can hold live indices; the products run over the row groups that actually do (wave-uniform).
 template <int KSZ>
 __device__ __forceinline__ void psd_project_ns(d4& a, const bool (&live)[4], const double eps, double* T, const int g,
                                                const int c) {
-    constexpr double QA = 3.4445, QB = -4.7750, QC = 2.0315;
-    constexpr int MAX_PAIRS = 18, MAX_CUBIC = 12;
     int flip = 0;
     d4 id, x;
 #pragma unroll
@@ -94,7 +130,8 @@ __device__ __forceinline__ void psd_project_ns(d4& a, const bool (&live)[4], con
     // needs ~log(|X| / eps) booster steps to resolve it.
     const bool nzl = (a[0] != 0.0) | (a[1] != 0.0) | (a[2] != 0.0) | (a[3] != 0.0);
     const unsigned long long bal = __builtin_amdgcn_ballot_w64(nzl);
-    const bool colnz = ((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) >> c) & 1ull;
+    const unsigned colmask = (unsigned)((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFull);
+    const bool colnz = (colmask >> c) & 1u;
     d4 idr;
 #pragma unroll
     for (int r = 0; r < 4; ++r) idr[r] = (live[r] && colnz) ? 1.0 : 0.0;
@@ -104,43 +141,19 @@ __device__ __forceinline__ void psd_project_ns(d4& a, const bool (&live)[4], con
 #pragma unroll
     for (int r = 0; r < 4; ++r) ss = __builtin_fma(x[r], x[r], ss);
     ss = ns_wave_sum(ss);
-    const double inv = (ss > 0.0) ? 1.0 / sqrt(ss) : 0.0;
-    d4 z;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) z[r] = x[r] * inv;
-    int pairs = 0, cubic = 0;
+    d4 ax = zero4();
     if (ss > 0.0) {   // X = 0: |X| = 0, nothing to iterate
-        for (;;) {
-            d4 z2 = ns_op<KSZ>(z, z);
-            double f = 0.0;
+        const double inv = 1.0 / sqrt(ss);
+        d4 z;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double e = idr[r] - z2[r];
-                f = __builtin_fma(e, e, f);
-            }
-            f = ns_wave_sum(f);
-            if (f > 0.9 && pairs < MAX_PAIRS) {
-                const d4 z4 = ns_op<KSZ>(z2, z2);
-                d4 w;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) w[r] = __builtin_fma(QC, z4[r], __builtin_fma(QB, z2[r], QA * idr[r]));
-                z = ns_symmetrise(ns_op<KSZ>(z, w), T, flip, g, c);
-                z2 = ns_op<KSZ>(z, z);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) w[r] = 1.5 * idr[r] - 0.5 * z2[r];
-                z = ns_symmetrise(ns_op<KSZ>(z, w), T, flip, g, c);
-                ++pairs;
-            } else {
-                d4 w;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) w[r] = 1.5 * idr[r] - 0.5 * z2[r];
-                z = ns_symmetrise(ns_op<KSZ>(z, w), T, flip, g, c);
-                ++cubic;
-                if (f < 1e-16 || cubic >= MAX_CUBIC) break;
-            }
-        }
+        for (int r = 0; r < 4; ++r) z[r] = x[r] * inv;
+        // nonzero columns all below row group `need`: the higher groups of every iterate stay zero and are skipped
+        const int need = (colmask >> 12) ? 4 : (colmask >> 8) ? 3 : (colmask >> 4) ? 2 : 1;
+        if (KSZ >= 4 && need == 4) ax = ns_sign_times<(KSZ >= 4 ? 4 : KSZ)>(z, x, idr, T, flip, g, c);
+        else if (KSZ >= 3 && need == 3) ax = ns_sign_times<(KSZ >= 3 ? 3 : KSZ)>(z, x, idr, T, flip, g, c);
+        else if (KSZ >= 2 && need == 2) ax = ns_sign_times<(KSZ >= 2 ? 2 : KSZ)>(z, x, idr, T, flip, g, c);
+        else ax = ns_sign_times<1>(z, x, idr, T, flip, g, c);
     }
-    const d4 ax = ns_op<KSZ>(z, x);   // |X| = sign(X) X
     d4 p;
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[r] = __builtin_fma(0.5, x[r] + ax[r], eps * id[r]);
