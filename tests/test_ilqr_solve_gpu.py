@@ -227,3 +227,63 @@ def test_pytree_expansion_constructors():
     assert np.max(np.abs(vf.v_x - (Qf + Qf.T) @ xf)) <= 1e-12 and np.array_equal(vf.v_xx, Qf + Qf.T)
     with pytest.raises(TypeError):
         pytrees.AffineDynamics.from_function(lambda x, u: x, xT[0, 0], uT[0, 0])
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 5, 6, 7])
+def test_ensurePositiveDefinite_adversarial_spectra(mods, kind):
+    """K5 computes V max(w, eps) V^T without an eigen-decomposition (matrix-sign iterations on the MFMA tile, ns16.h; NumPy model
+    in tools/ns_psd_model.py): the spectra that stress it -- many decades of magnitude, eigenvalues hugging eps from both
+    sides, rank one, dominant pairs, exactly zero rows/columns (the structure of the DDP Hessians of a model that is affine in
+    some variables), everything already PD -- against eigh (reference ilqrUtils.py:217-225).  Tolerance 2e-11 relative to the
+    largest entry of the result (the iteration resolves eigenvalues of a - eps I down to ~1e-12 of its norm)."""
+    ilqr = mods[0]
+    rng = np.random.default_rng(100 + kind)
+    mats = []
+    for t in range(24):
+        k = int(rng.integers(2, 17))
+        Q, _ = np.linalg.qr(rng.standard_normal((k, k)))
+        if kind == 0:
+            lam = rng.standard_normal(k) * 10 ** rng.uniform(-3, 3)
+        elif kind == 1:
+            lam = np.concatenate([rng.standard_normal(k // 2), 1e-3 + rng.standard_normal(k - k // 2) * 1e-9])
+        elif kind == 2:
+            lam = 10.0 ** rng.uniform(-14, 2, k) * rng.choice([-1, 1], k)
+        elif kind == 3:
+            lam = np.zeros(k)
+            lam[0] = rng.standard_normal()
+        elif kind == 4:
+            lam = rng.standard_normal(k)
+            lam[:2] = 1e3
+        elif kind == 5:
+            lam = 1e-3 + 10.0 ** rng.uniform(-16, -2, k) * rng.choice([-1, 1], k)
+        elif kind == 6:      # exactly zero rows / columns around a dense block
+            lam = rng.standard_normal(k) * 10 ** rng.uniform(0, 2)
+        else:                # already positive definite, wide range
+            lam = 10.0 ** rng.uniform(-2, 4, k)
+        a = (Q * lam) @ Q.T
+        a = 0.5 * (a + a.T)
+        if kind == 6:
+            dead = rng.choice(k, size=max(1, k // 3), replace=False)
+            a[dead, :] = 0.0
+            a[:, dead] = 0.0
+        A = np.zeros((16, 16))
+        A[:k, :k] = a
+        mats.append((k, a))
+    for k in sorted({k for k, _ in mats}):
+        batch = np.stack([a for kk, a in mats if kk == k])
+        out = ilqr.ensurePositiveDefinite(batch)
+        ref = zo.ensurePositiveDefinite(batch)
+        for o, r in zip(out, ref):
+            assert np.max(np.abs(o - r)) <= 2e-11 * max(np.max(np.abs(r)), 1e-3)
+            assert np.min(np.linalg.eigvalsh(0.5 * (o + o.T))) >= 1e-3 * (1 - 1e-6)
+
+
+def test_ensurePositiveDefinite_nonfinite_and_zero(mods):
+    ilqr = mods[0]
+    A = np.zeros((3, 5, 5))
+    A[1] = np.nan
+    A[2, 0, 0] = np.inf
+    out = ilqr.ensurePositiveDefinite(A)
+    assert out[0] == pytest.approx(1e-3 * np.eye(5), abs=0)        # the zero matrix: eps I exactly
+    assert np.all(np.isnan(out[1]))                                  # eigh of NaN is NaN
+    assert not np.all(np.isfinite(out[2]))
