@@ -109,6 +109,12 @@ def lib():
             raise ZoptAmdError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(zopt_amd has no CPU fallback)")
+        # torch first: its wheel bundles its own HIP runtime, and the library must bind to THAT copy (same SONAME) -- loaded the
+        # other way round, two runtimes end up in the process and the first launch fails with "no ROCm-capable device"
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover
+            pass
         try:
             handle = ctypes.CDLL(LIB_PATH)
         except OSError as e:  # pragma: no cover
