@@ -143,6 +143,9 @@ typedef struct zm_quadcost_t {
     const double* Q;        /* (n,n) */
     const double* R;        /* (m,m) */
     const double* Qf;       /* (n,n) */
+    int32_t diagonal;       /* 1: the caller asserts that Q, R and Qf are diagonal (the demos' weights) -- off-diagonal entries are
+                               then never read and the rollout runs a leaner kernel; 0: unknown, the kernels look for themselves */
+    int32_t reserved;
 } zm_quadcost_t;
 
 /* Batched policy rollout with a parallel line search over step sizes.

@@ -187,3 +187,43 @@ def test_cost_function_call_matches_reference_definition():
     j2 = cost(pytrees.Trajectory(xT[1], uT[1]), k=2)
     assert abs(j2 - (xT[1, 2] @ Q @ xT[1, 2] + uT[1, 2] @ R @ uT[1, 2])) <= 1e-12
     assert isinstance(cost(pytrees.Trajectory(xT[0], uT[0])), float)
+
+
+@pytest.mark.parametrize("kind", ["linear", "quadcopter"])
+def test_diagonal_weight_kernels_agree(mods, kind):
+    """Diagonal Q, R, Qf (the demos' weights) run a leaner rollout kernel when the cost handle says so
+    (`zm_quadcost_t.diagonal`, set by zopt_amd.models.QuadraticCost from the matrices themselves); with the hint cleared the
+    general kernel finds the diagonal structure itself.  Both against the oracle and bit for bit against each other."""
+    ilqr, models, pt = mods
+    rng = np.random.default_rng(5)
+    batch, N, n, m = 9, 30, 12, 4
+    if kind == "linear":
+        model = models.LinearModel(rng.standard_normal((n, n)) * (1.05 / np.sqrt(n)), rng.standard_normal((n, m)))
+        x0, l, L, xPrev, uPrev = _random_policy_problem(rng, batch, N, n, m)
+        l *= 4.0
+        f = model
+    else:
+        model = models.QuadcopterEuler(0.1)
+        x0, l, L, xPrev, uPrev = _quad_problem(rng, batch, N)
+        l *= 60.0
+        f = zo.quad_euler_step(0.1)
+    Q, R, Qf = np.diag(rng.uniform(0.5, 2.0, n)), np.diag(rng.uniform(0.5, 2.0, m)), np.diag(rng.uniform(5.0, 20.0, n))
+    cost = models.QuadraticCost(Q, R, Qf)
+    assert cost.c_struct().diagonal == 1
+    assert models.QuadraticCost(Q + 1e-300 * np.eye(n, k=1), R, Qf).c_struct().diagonal == 0
+
+    class Unhinted(models.QuadraticCost):
+        def c_struct(self):
+            s = super().c_struct()
+            s.diagonal = 0
+            return s
+
+    pol, prev = pt.AffinePolicy(l, L), pt.Trajectory(xPrev, uPrev)
+    traj, J = ilqr.forwardPass2(x0, model, cost, pol, prev)
+    traj0, J0 = ilqr.forwardPass2(x0, model, Unhinted(Q, R, Qf), pol, prev)
+    assert np.array_equal(J, J0) and np.array_equal(traj.xTraj, traj0.xTraj) and np.array_equal(traj.uTraj, traj0.uTraj)
+    for b in range(batch):
+        rt, rJ = zo.forwardPass2(x0[b], f, cost.runningCost, cost.terminalCost, zo.AffinePolicy(l[b], L[b]),
+                                 zo.Trajectory(xPrev[b], uPrev[b]))
+        assert abs(J[b] - rJ) <= 1e-10 * abs(rJ)
+        assert _rel(traj.xTraj[b], rt.xTraj) <= 1e-9 and _rel(traj.uTraj[b], rt.uTraj) <= 1e-9

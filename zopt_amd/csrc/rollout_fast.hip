@@ -262,7 +262,10 @@ __device__ __forceinline__ void rollout_ls_body(const FastArgs& g, const double*
     }
 }
 
-template <int KIND>
+// DIAG_ONLY: the caller asserted diagonal weights (zm_quadcost_t.diagonal): only the diagonal path is compiled in -- 158 VGPRs, three
+// waves per SIMD.  Otherwise the kernel decides per launch; it then also carries the general path, whose hoisted weight matrices
+// cost it 458 registers (one wave per SIMD) on either branch.
+template <int KIND, bool DIAG_ONLY>
 __global__ __launch_bounds__(64) void rollout_ls_fast_kernel(const FastArgs g) {
     __shared__ double Qs[RN * RN], Rs[RM * RM], Qfs[RN * RN];
     __shared__ double As[KIND == ZM_MODEL_LINEAR ? RN * RN : 1], Bs[KIND == ZM_MODEL_LINEAR ? RN * RM : 1];
@@ -285,31 +288,38 @@ __global__ __launch_bounds__(64) void rollout_ls_fast_kernel(const FastArgs g) {
         for (int e = lane; e < RN * RM; e += 64) Bs[e] = g.B[e];
     }
     __syncthreads();
-    // diagonal weights (the demos' Q = I, R = I, Qf = 10 I): x^T W x costs n FMAs instead of n^2; decided per launch,
-    // wave-uniform
-    if (__ballot(offdiag) == 0ull)
+    if constexpr (DIAG_ONLY) {
         rollout_ls_body<KIND, true>(g, Qs, Rs, Qfs, As, Bs, pol);
-    else
-        rollout_ls_body<KIND, false>(g, Qs, Rs, Qfs, As, Bs, pol);
+    } else {
+        // diagonal weights (the demos' Q = I, R = I, Qf = 10 I): x^T W x costs n FMAs instead of n^2; wave-uniform
+        if (__ballot(offdiag) == 0ull)
+            rollout_ls_body<KIND, true>(g, Qs, Rs, Qfs, As, Bs, pol);
+        else
+            rollout_ls_body<KIND, false>(g, Qs, Rs, Qfs, As, Bs, pol);
+    }
 }
 
 template <int KIND>
-static int launch_fast(const FastArgs& g, hipStream_t st) {
+static int launch_fast(const FastArgs& g, const bool diag_only, hipStream_t st) {
     const long nslot = g.list ? g.count : g.batch;
-    hipLaunchKernelGGL((rollout_ls_fast_kernel<KIND>), dim3((unsigned)((nslot + 3) / 4)), dim3(64), 0, st, g);
+    const dim3 grid((unsigned)((nslot + 3) / 4)), block(64);
+    if (diag_only)
+        hipLaunchKernelGGL((rollout_ls_fast_kernel<KIND, true>), grid, block, 0, st, g);
+    else
+        hipLaunchKernelGGL((rollout_ls_fast_kernel<KIND, false>), grid, block, 0, st, g);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }
 
 // Fast path dispatch: (n, m) = (12, 4), 16 step sizes.
-int rollout_fast_dispatch(const zm_model_t& md, const double* Q, const double* R, const double* Qf,
+int rollout_fast_dispatch(const zm_model_t& md, const double* Q, const double* R, const double* Qf, int diagonal,
                           const double* x0, const double* l, const double* L, const double* xPrev, const double* uPrev,
                           const double* alphas, const int* active, const int* list, int64_t count, double* xTraj,
                           double* uTraj, double* J, int* idx, int64_t batch, int T, hipStream_t st) {
     FastArgs g{md.A, md.B, md.dt, Q, R, Qf, x0, l, L, xPrev, uPrev, alphas, active, list, (long)count, xTraj, uTraj, J, idx,
                (long)batch, T};
-    if (md.kind == ZM_MODEL_QUADCOPTER) return launch_fast<ZM_MODEL_QUADCOPTER>(g, st);
-    return launch_fast<ZM_MODEL_LINEAR>(g, st);
+    if (md.kind == ZM_MODEL_QUADCOPTER) return launch_fast<ZM_MODEL_QUADCOPTER>(g, diagonal == 1, st);
+    return launch_fast<ZM_MODEL_LINEAR>(g, diagonal == 1, st);
 }
 
 }  // namespace zm

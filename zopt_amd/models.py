@@ -24,7 +24,8 @@ class zm_model_t(ctypes.Structure):
 
 
 class zm_quadcost_t(ctypes.Structure):
-    _fields_ = [("Q", ctypes.c_void_p), ("R", ctypes.c_void_p), ("Qf", ctypes.c_void_p)]
+    _fields_ = [("Q", ctypes.c_void_p), ("R", ctypes.c_void_p), ("Qf", ctypes.c_void_p), ("diagonal", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 
 class LinearModel:
@@ -99,7 +100,9 @@ class QuadraticCost:
         import torch
         if self._dev is None:
             self._dev = tuple(arr.to_device(X, torch.float64) for X in (self.Q, self.R, self.Qf))
-        return zm_quadcost_t(*[t.data_ptr() for t in self._dev])
+        isdiag = lambda M: not np.any(M - np.diag(np.diagonal(M)))          # exact: also False for NaN off the diagonal
+        diag = int(isdiag(self.Q) and isdiag(self.R) and isdiag(self.Qf))
+        return zm_quadcost_t(*[t.data_ptr() for t in self._dev], diag, 0)
 
 
 class QuadcopterRigidBody:
