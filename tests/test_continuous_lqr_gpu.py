@@ -206,3 +206,26 @@ def test_riccati_ode_edge_cases(lqr):
     s2 = np.sqrt(2)
     k0 = ((1 + s2) * np.exp(2 * s2) - (s2 - 1)) / (1 + np.exp(2 * s2))
     assert K(0.0).cpu().numpy() == pytest.approx(k0 * I2, rel=1e-7)
+
+
+def test_riccati_ode_failures_are_reported(lqr):
+    """A step cap that is too small and a Riccati flow with a finite escape time (Q = -100 I: dV/ds = Q - V^2 reaches -inf at
+    s = atan(0.1)/10 + pi/20 ~ 0.167) end with info < 0 and NaN at the output times that were not reached; the terminal
+    value (t = T) is always delivered."""
+    c = lambda t: I2
+    K = lqr.finiteHorizonLqr(c, c, c, c, I2, 1.0, N=6, max_steps=3)
+    assert int(K.info) == -1
+    assert K.V[-1] == pytest.approx(I2) and np.all(np.isnan(K.V[0]))
+    zero = lambda t: np.zeros((2, 2))
+    K = lqr.finiteHorizonLqr(zero, c, lambda t: -100.0 * I2, c, I2, 1.0, N=6)
+    assert int(K.info) < 0
+    assert K.V[-1] == pytest.approx(I2) and np.all(np.isnan(K.V[0]))
+    # a batch in which only one design fails: the others are unaffected
+    Qb = lambda t: np.stack([I2, -100.0 * I2, I2])
+    cb = lambda t: np.stack([I2, I2, I2])
+    Ab = lambda t: np.stack([I2, 0 * I2, I2])
+    K = lqr.finiteHorizonLqr(Ab, cb, Qb, cb, np.stack([I2, I2, I2]), 1.0, N=4)
+    assert K.info[0] > 0 and K.info[1] < 0 and K.info[2] > 0
+    s2 = np.sqrt(2)
+    k0 = ((1 + s2) * np.exp(2 * s2) - (s2 - 1)) / (1 + np.exp(2 * s2))
+    assert K.V[0, 0] == pytest.approx(k0 * I2, rel=1e-7) and K.V[2, 0] == pytest.approx(k0 * I2, rel=1e-7)
