@@ -35,9 +35,9 @@ def ns_projection(A, k, eps=1e-3, stats=None):
         F = np.sum((I - Z2) ** 2)
         if F > 0.9 and pairs < MAX_PAIRS:
             Z4 = Z2.T @ Z2
-            Z = sym(Z.T @ (QA * I + QB * Z2 + QC * Z4))
+            Z = (QA * I + QB * Z2 + QC * Z4).T @ Z        # W bitwise symmetric: W^T Z = W Z; symmetrised after the cubic step
             Z2 = Z.T @ Z
-            Z = sym(Z.T @ (1.5 * I - 0.5 * Z2))
+            Z = sym((1.5 * I - 0.5 * Z2).T @ Z)
             mfma += 16
             pairs += 1
         else:

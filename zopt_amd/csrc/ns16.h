@@ -97,11 +97,13 @@ __device__ __forceinline__ d4 ns_sign_times(d4 z, const d4& x, const d4& idr, do
             const d4 z4 = ns_op<K>(z2, z2);
 #pragma unroll
             for (int r = 0; r < 4; ++r) w[r] = __builtin_fma(QC, z4[r], __builtin_fma(QB, z2[r], QA * idr[r]));
-            z = ns_symmetrise(ns_op<K>(z, w), T, flip, g, c);
+            // W is bitwise symmetric (built from Z^T Z and its square): W^T Z = W Z needs no transpose of Z, and the booster's
+            // result may stay unsymmetrised until the cubic step that follows (tools/ns_psd_model.py: same accuracy)
+            z = ns_op<K>(w, z);
             z2 = ns_op<K>(z, z);
 #pragma unroll
             for (int r = 0; r < 4; ++r) w[r] = 1.5 * idr[r] - 0.5 * z2[r];
-            z = ns_symmetrise(ns_op<K>(z, w), T, flip, g, c);
+            z = ns_symmetrise(ns_op<K>(w, z), T, flip, g, c);
             ++pairs;
         } else {
 #pragma unroll
