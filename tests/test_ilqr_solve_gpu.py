@@ -287,3 +287,50 @@ def test_ensurePositiveDefinite_nonfinite_and_zero(mods):
     assert out[0] == pytest.approx(1e-3 * np.eye(5), abs=0)        # the zero matrix: eps I exactly
     assert np.all(np.isnan(out[1]))                                  # eigh of NaN is NaN
     assert not np.all(np.isfinite(out[2]))
+
+
+def test_iterativeLqr_baseline_config4_full_size(mods):
+    """BASELINE configs[3] at full size: 8192 quadcopter iLQR problems, T = 100, x0[9:12] ~ U(-10, 10)^3, uGuess = uTrim
+    (tools/bench_ilqr.py's workload).  Size-independent properties on the whole batch, the oracle loop on a few trajectories,
+    and batch-composition independence (a trajectory solved alone gives the same answer as inside the 8192)."""
+    ilqr, models, pt, _ = mods
+    batch, N = 8192, 100
+    Q, R, Qf = np.eye(12), np.eye(4), 10 * np.eye(12)
+    cost = models.QuadraticCost(Q, R, Qf)
+    model = models.QuadcopterEuler(0.1)
+    rng = np.random.default_rng(2)
+    x0 = np.zeros((batch, 12))
+    x0[:, 9:12] = rng.uniform(-10, 10, (batch, 3))
+    ug = np.tile(models.QuadcopterEuler.uTrim, (batch, N, 1))
+    traj, L, J, conv = ilqr.iterativeLqr(model, cost, cost, x0, ug)
+    assert traj.xTraj.shape == (batch, N + 1, 12) and L.shape == (batch, N, 4, 12) and J.shape == (batch,)
+    assert conv.mean() > 0.85                                   # most starts converge within 100 iterations
+    # the initial guess hovers at x0: J0 = N (x0'Q x0 + uTrim'R uTrim) + x0'Qf x0; every converged solve improved on it
+    uT = models.QuadcopterEuler.uTrim
+    J0 = (N + 10) * np.sum(x0 ** 2, axis=1) + N * float(uT @ R @ uT)
+    assert np.all(J[conv] < J0[conv])
+    assert np.all(np.isfinite(traj.xTraj[conv])) and np.all(np.isfinite(L[conv]))
+    assert np.all(traj.xTraj[:, 0] == x0)                        # rollouts start at x0 exactly
+    # the returned trajectory is the rollout of its own controls and J is its cost
+    step = zo.quad_euler_step(0.1)
+    pick = [0, 1234, 4095, 8191, int(np.flatnonzero(~conv)[0])] if (~conv).any() else [0, 1234, 4095, 8191]
+    for i in pick[:4]:
+        x = x0[i].copy()
+        Ji = 0.0
+        for k in range(N):
+            Ji += x @ Q @ x + traj.uTraj[i, k] @ R @ traj.uTraj[i, k]
+            x = step(x, traj.uTraj[i, k])
+            assert np.max(np.abs(x - traj.xTraj[i, k + 1])) <= 1e-9 * max(1.0, np.max(np.abs(x)))
+        Ji += x @ Qf @ x
+        assert J[i] == pytest.approx(Ji, rel=1e-10)
+    # oracle loop (iteration-by-iteration the same decisions) on two converged trajectories
+    for i in pick[:2]:
+        rt, rL, rJ, rc = zo.iterativeLqr(step, Q, R, Qf, x0[i], ug[i])
+        assert bool(conv[i]) == rc and J[i] == pytest.approx(rJ, rel=1e-7)
+        assert _rel(traj.uTraj[i], rt.uTraj) <= 1e-6 and _rel(L[i], rL) <= 1e-6
+    # batch-composition independence, including a start that does not converge
+    sub = np.array(pick)
+    ts, Ls, Js, cs = ilqr.iterativeLqr(model, cost, cost, x0[sub], ug[sub])
+    assert np.array_equal(cs, conv[sub])
+    assert np.array_equal(Js, J[sub], equal_nan=True)
+    assert np.array_equal(ts.uTraj, traj.uTraj[sub], equal_nan=True) and np.array_equal(Ls, L[sub], equal_nan=True)
