@@ -50,7 +50,8 @@ __device__ __forceinline__ void fast_step(const double* As, const double* Bs, co
         zm_sincos(x[6], &sphi, &cphi);
         zm_sincos(x[7], &sth, &cth);
         zm_sincos(x[8], &spsi, &cpsi);
-        const double tth = sth / cth;
+        const double icth = 1.0 / cth;   // one division: tan(theta) = sin * (1 / cos), and the two quotients of the psi-dot row
+        const double tth = sth * icth;
         const double fa0 = -0.2 * x[0] + -0.05 * (x[0] * x[0]);
         const double fa1 = -0.2 * x[1] + -0.05 * (x[1] * x[1]);
         const double fa2 = -0.3 * x[2] + -0.1 * (x[2] * x[2]);
@@ -69,7 +70,7 @@ __device__ __forceinline__ void fast_step(const double* As, const double* Bs, co
         xd[5] = u[3] + -0.05 * x[5];
         xd[6] = (x[3] + (sphi * tth) * x[4]) + (cphi * tth) * x[5];
         xd[7] = cphi * x[4] - sphi * x[5];
-        xd[8] = (sphi / cth) * x[4] + (cphi / cth) * x[5];
+        xd[8] = (sphi * icth) * x[4] + (cphi * icth) * x[5];
         xd[9] = ((cth * cpsi) * x[0] + (sphi * sth * cpsi - cphi * spsi) * x[1]) + (cphi * sth * cpsi - sphi * spsi) * x[2];
         xd[10] = ((cth * spsi) * x[0] + (sphi * sth * spsi + cphi * cpsi) * x[1]) + (cphi * sth * spsi - sphi * cpsi) * x[2];
         xd[11] = ((-sth) * x[0] + (sphi * cth) * x[1]) + (cphi * cth) * x[2];
