@@ -216,6 +216,7 @@ int zm_ilqr_backward_ex_f64(const double* f_x, const double* f_u, const double* 
  *     Q_xx += vf_xx, Q_uu += vf_uu, Q_ux += vf_ux, then the iLQR step.
  * in : as zm_ilqr_backward_ex_f64, plus QuadraticDynamics (pytrees.py:165-177)
  *      f_xx (batch,T,n,n,n)  f_ux (batch,T,n,m,n)  f_uu (batch,T,n,m,m)     [f_..[i,j,k] = d2 f_i / d._j d._k]
+ *      (f_ux and f_uu both NULL: identically zero, i.e. dynamics affine in the controls)
  * out: l (batch,T,m)  L (batch,T,m,n)
  */
 int zm_ddp_backward_f64(const double* f_x, const double* f_u, const double* f_xx, const double* f_ux, const double* f_uu,
@@ -234,10 +235,16 @@ int zm_riccati_value_f64(const double* f_x, const double* f_u, const double* f_x
                          const double* c_uu, const double* vf, const double* vf_x, const double* vf_xx, double* l, double* L,
                          double* v_out, double* vx_out, double* vxx_out, int64_t batch, int T, int n, int m, void* stream);
 
+/* Variables in which a registered model is NOT affine: bit i = state i, bit n + j = control j.  Only pairs of these have a nonzero
+ * second derivative -- the second-order expansion evaluates only those pairs, and a driver need not materialise the zero blocks. */
+int zm_model_nonlinear_mask(const zm_model_t* model, uint32_t* mask);
+
 /* Second-order expansion of a registered model along a trajectory (forward-mode hyper-dual numbers).
  * Replaces: zopt/pytrees.py:180-194 QuadraticDynamics.from_function / from_trajectory (jax.hessian of dynFun):
  * in : xTraj (batch,T+1,n)  uTraj (batch,T,m)  active or NULL
  * out: f_xx (batch,T,n,n,n)  f_ux (batch,T,n,m,n)  f_uu (batch,T,n,m,m)
+ *      f_ux and f_uu may both be NULL for a model that is affine in its controls (no control bit in zm_model_nonlinear_mask):
+ *      they are identically zero and zm_ddp_backward_f64 / zm_riccati_value_f64 take NULL for them as well.
  */
 int zm_quadratic_dynamics_f64(const zm_model_t* model, const double* xTraj, const double* uTraj, const int32_t* active,
                               double* f_xx, double* f_ux, double* f_uu, int64_t batch, int T, void* stream);

@@ -137,3 +137,56 @@ def test_conditionQuadraticDynamics_matches_oracle():
         sc = max(np.max(np.abs(rxx)), 1.0)
         assert np.max(np.abs(gxx - rxx)) <= 1e-10 * sc and np.max(np.abs(gux - rux)) <= 1e-10 * sc
         assert np.max(np.abs(guu - ruu)) <= 1e-10 * sc
+
+
+def test_control_affine_models_skip_the_zero_blocks(mods):
+    """`zm_model_nonlinear_mask` declares the variables a registered model is not affine in (quadcopter: the 9 velocity / rate / angle
+    states; linear model: none).  The autograd oracle confirms every other second derivative is zero; the second-order expansion and
+    the DDP sweep accept NULL for f_ux / f_uu of such a model and give bit-identical results to zero tensors."""
+    import ctypes
+    import torch
+    ilqr, models, _, _lib = mods
+    lib = _lib.lib()
+    mask = ctypes.c_uint32(123)
+    md = models.QuadcopterEuler(0.1).c_struct()
+    assert lib.zm_model_nonlinear_mask(ctypes.addressof(md), ctypes.byref(mask)) == 0 and mask.value == 0x1FF
+    mdl = models.LinearModel(np.eye(3), np.ones((3, 2))).c_struct()
+    assert lib.zm_model_nonlinear_mask(ctypes.addressof(mdl), ctypes.byref(mask)) == 0 and mask.value == 0
+    assert lib.zm_model_nonlinear_mask(None, ctypes.byref(mask)) == _lib.ZM_EINVAL
+    # oracle: all second derivatives outside the declared 9 x 9 block vanish
+    rng = np.random.default_rng(4)
+    b, N = 2, 4
+    xT = 0.5 * rng.standard_normal((b, N + 1, 12))
+    uT = np.array([9.807, 0, 0, 0]) + rng.standard_normal((b, N, 4))
+    ref = zo.quadratic_dynamics_from_trajectory(zo.quad_euler_step_torch(0.1), zo.Trajectory(xT[0], uT[0]))
+    assert np.all(ref.f_ux == 0) and np.all(ref.f_uu == 0) and np.all(ref.f_xx[:, :, 9:, :] == 0) and np.all(ref.f_xx[:, :, :, 9:] == 0)
+    # expansion with and without the zero blocks
+    dx, du = torch.as_tensor(xT, device="cuda"), torch.as_tensor(uT, device="cuda")
+    t = lambda *s: torch.full(s, float("nan"), dtype=torch.float64, device="cuda")
+    f_xx, f_ux, f_uu, g_xx = t(b, N, 12, 12, 12), t(b, N, 12, 4, 12), t(b, N, 12, 4, 4), t(b, N, 12, 12, 12)
+    pm = ctypes.addressof(md)
+    assert lib.zm_quadratic_dynamics_f64(pm, dx.data_ptr(), du.data_ptr(), None, f_xx.data_ptr(), f_ux.data_ptr(), f_uu.data_ptr(),
+                                         b, N, None) == 0
+    assert lib.zm_quadratic_dynamics_f64(pm, dx.data_ptr(), du.data_ptr(), None, g_xx.data_ptr(), None, None, b, N, None) == 0
+    assert lib.zm_quadratic_dynamics_f64(pm, dx.data_ptr(), du.data_ptr(), None, g_xx.data_ptr(), f_ux.data_ptr(), None,
+                                         b, N, None) == _lib.ZM_EINVAL          # f_ux and f_uu go together
+    torch.cuda.synchronize()
+    assert torch.equal(f_xx, g_xx) and not bool(f_ux.any()) and not bool(f_uu.any())
+    # sweep with zero tensors vs NULL
+    dyn, cost, Vf = problems.random_ilqr_model(b, N, 12, 4, seed=3)
+    dev = [torch.as_tensor(np.ascontiguousarray(X), device="cuda") for X in (dyn[1], dyn[2], cost[1], cost[2], cost[3], cost[4], cost[5],
+                                                                             Vf[1], Vf[2])]
+    outs = []
+    for ux, uu in ((f_ux, f_uu), (None, None)):
+        l, L = t(b, N, 4), t(b, N, 4, 12)
+        rc = lib.zm_ddp_backward_f64(dev[0].data_ptr(), dev[1].data_ptr(), f_xx.data_ptr(), ux.data_ptr() if ux is not None else None,
+                                     uu.data_ptr() if uu is not None else None, *[d.data_ptr() for d in dev[2:]], None, 0,
+                                     l.data_ptr(), L.data_ptr(), b, N, 12, 4, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        outs.append((l.cpu().numpy(), L.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    refp = zo.backwardPass_ddp(zo.QuadraticDynamics(dyn[0][0], dyn[1][0], dyn[2][0], f_xx[0].cpu().numpy(), f_ux[0].cpu().numpy(),
+                                                    f_uu[0].cpu().numpy()),
+                               zo.QuadraticCostFunction(*[c[0] for c in cost]), zo.QuadraticValueFunction(*[v[0] for v in Vf]))
+    assert _rel(outs[1][1][0], refp.L) <= 1e-9 and _rel(outs[1][0][0], refp.l) <= 1e-9

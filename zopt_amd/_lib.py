@@ -77,6 +77,7 @@ SYMBOLS = {
                             [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     # (model*, xTraj, uTraj, active, f_xx, f_ux, f_uu, batch, T, stream)
     "zm_quadratic_dynamics_f64": (ctypes.c_int, [_c_dp] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "zm_model_nonlinear_mask": (ctypes.c_int, [_c_dp, _c_dp]),
     "zm_psd_project_f64": (ctypes.c_int, [_c_dp, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
     "zm_condition_cost_f64": (ctypes.c_int, [_c_dp] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                                           ctypes.c_void_p]),

@@ -373,7 +373,10 @@ __global__ __launch_bounds__(64, 2) void ilqr_backward_t16_f64(
             const int cb = cA ? c : (cB ? n + (c - NP) : -1);
             a.zc[r] = (ca >= 0 && cb >= 0) ? ca * PLD + cb : -1;
             a.zlive[r] = (ca >= 0) && (row == c);
-            if (rx && cA) {            // f_xx[i][row][c]
+            if (f_ux == nullptr && !(rx && cA)) {   // dynamics affine in the controls: f_ux, f_uu are zero and not materialised
+                a.zc[r] = -1;
+                a.pz[r] = fxxt;  a.sz[r] = 0;  a.stz[r] = (int)nnn;
+            } else if (rx && cA) {     // f_xx[i][row][c]
                 a.pz[r] = fxxt + row * n + c;  a.sz[r] = nn;  a.stz[r] = (int)nnn;
             } else if (rx && cB) {     // (vf_ux)^T: f_ux[i][c-NP][row]
                 a.pz[r] = fuxt + (c - NP) * n + row;  a.sz[r] = nm;  a.stz[r] = (int)nmn;
@@ -772,8 +775,8 @@ extern "C" int zm_ddp_backward_f64(const double* f_x, const double* f_u, const d
                                    const int32_t* active, int shared_hessian, double* l, double* L, int64_t batch, int T,
                                    int n, int m, void* stream) {
     if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
-    if (!f_x || !f_u || !f_xx || !f_ux || !f_uu || !c_x || !c_u || !c_xx || !c_ux || !c_uu || !vf_x || !vf_xx || !l || !L)
-        return zm::set_error(ZM_EINVAL, "zm_ddp_backward_f64: null pointer");
+    if (!f_x || !f_u || !f_xx || (!f_ux != !f_uu) || !c_x || !c_u || !c_xx || !c_ux || !c_uu || !vf_x || !vf_xx || !l || !L)
+        return zm::set_error(ZM_EINVAL, "zm_ddp_backward_f64: null pointer (f_ux and f_uu may be NULL together: identically zero)");
     const int rc = zm_check_sweep_args("zm_ddp_backward_f64", batch, T, n, m);
     if (rc) return rc;
     if ((int64_t)n * n * n >= (int64_t)1 << 31) return zm::set_error(ZM_EUNSUPPORTED, "zm_ddp_backward_f64: n too large");
@@ -792,7 +795,8 @@ extern "C" int zm_riccati_value_f64(const double* f_x, const double* f_u, const 
     if (!f_x || !f_u || !c_x || !c_u || !c_xx || !c_ux || !c_uu || !vf_x || !vf_xx || !l || !L)
         return zm::set_error(ZM_EINVAL, "zm_riccati_value_f64: null pointer");
     const bool ddp = f_xx || f_ux || f_uu;
-    if (ddp && (!f_xx || !f_ux || !f_uu)) return zm::set_error(ZM_EINVAL, "zm_riccati_value_f64: f_xx, f_ux, f_uu go together");
+    if (ddp && (!f_xx || (!f_ux != !f_uu)))
+        return zm::set_error(ZM_EINVAL, "zm_riccati_value_f64: f_xx goes with f_ux and f_uu (the latter two may be NULL together: zero)");
     const int rc = zm_check_sweep_args("zm_riccati_value_f64", batch, T, n, m);
     if (rc) return rc;
     const zm::ValueIO v{c, vf, v_out, vx_out, vxx_out};

@@ -82,8 +82,10 @@ __global__ __launch_bounds__(64) void quadratic_dynamics_kernel(const zm_model_t
     {
         const int nxx = n * n * n, nux = n * m * n, nuu = n * m * m;
         for (int e = threadIdx.x; e < nxx; e += 64) oxx[e] = 0.0;
-        for (int e = threadIdx.x; e < nux; e += 64) oux[e] = 0.0;
-        for (int e = threadIdx.x; e < nuu; e += 64) ouu[e] = 0.0;
+        if (f_ux) {   // NULL (with f_uu): the model is affine in its controls, the caller does not materialise these zeros
+            for (int e = threadIdx.x; e < nux; e += 64) oux[e] = 0.0;
+            for (int e = threadIdx.x; e < nuu; e += 64) ouu[e] = 0.0;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the zeros land before the entries written below
         __builtin_amdgcn_s_waitcnt(0);
     }
@@ -263,7 +265,10 @@ extern "C" int zm_quadratic_dynamics_f64(const zm_model_t* model, const double* 
     zm_model_t md;
     int rc = zm_check_model(model, md, "zm_quadratic_dynamics_f64");
     if (rc) return rc;
-    if (!xTraj || !uTraj || !f_xx || !f_ux || !f_uu) return zm::set_error(ZM_EINVAL, "zm_quadratic_dynamics_f64: null pointer");
+    if (!xTraj || !uTraj || !f_xx || (!f_ux != !f_uu)) return zm::set_error(ZM_EINVAL, "zm_quadratic_dynamics_f64: null pointer");
+    if (!f_ux && (zm::model_nonlinear_mask(md) >> md.n) != 0u)
+        return zm::set_error(ZM_EINVAL, "zm_quadratic_dynamics_f64: f_ux / f_uu may only be omitted for a model that is affine in its "
+                                        "controls (zm_model_nonlinear_mask)");
     if (batch < 0 || T < 1) return zm::set_error(ZM_EINVAL, "zm_quadratic_dynamics_f64: bad size");
     if (batch == 0) return ZM_OK;
     hipLaunchKernelGGL(zm::quadratic_dynamics_kernel, dim3((unsigned)(batch * T)), dim3(64), 0, (hipStream_t)stream, md, xTraj,
@@ -408,5 +413,14 @@ extern "C" int zm_quadcopter_trim_f64(const double* uvw, const double* wind_body
     hipLaunchKernelGGL(zm::quad_trim_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, (hipStream_t)stream, uvw, w0, w1, w2,
                        xTrim, uTrim, resid, (int*)ok, (long)batch, tol);
     ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+
+extern "C" int zm_model_nonlinear_mask(const zm_model_t* model, uint32_t* mask) {
+    zm_model_t md;
+    const int rc = zm_check_model(model, md, "zm_model_nonlinear_mask");
+    if (rc) return rc;
+    if (!mask) return zm::set_error(ZM_EINVAL, "zm_model_nonlinear_mask: null pointer");
+    *mask = zm::model_nonlinear_mask(md);
     return ZM_OK;
 }

@@ -161,7 +161,7 @@ __device__ __forceinline__ void quad_inertial_dynamics(const S (&x)[12], const S
 // Variables (bit i: state i; bit n + j: control j) in which the model is NOT affine: only pairs of these can have a nonzero
 // second derivative.  The quadcopter's controls enter linearly (thrust along body z and the three moments, quadcopter.py:94-105)
 // and its inertial position does not enter at all; a linear model has no such variable.
-__device__ __forceinline__ unsigned model_nonlinear_mask(const zm_model_t& md) {
+__host__ __device__ __forceinline__ unsigned model_nonlinear_mask(const zm_model_t& md) {
     if (md.kind == ZM_MODEL_QUADCOPTER) return 0x1FFu;      // u v w p q r phi theta psi
     if (md.kind == ZM_MODEL_QUADCOPTER_RB) return 0xFFu;    // u v w p q r phi theta
     return 0u;

@@ -400,8 +400,16 @@ def _ilqr_or_ddp(dynamics, runningCost, terminalCost, x0, uGuess, maxIter, tol, 
     v_x = torch.empty((B, n), dtype=dt, device=dev)
     if ddp:
         f_xx = torch.empty((B, N, n, n, n), dtype=dt, device=dev)
-        f_ux = torch.empty((B, N, n, m, n), dtype=dt, device=dev)
-        f_uu = torch.empty((B, N, n, m, m), dtype=dt, device=dev)
+        # a model that is affine in its controls has f_ux = f_uu = 0: neither written nor read (zm_model_nonlinear_mask)
+        nl_mask = ctypes.c_uint32(0)
+        _lib.check(lib.zm_model_nonlinear_mask(pmd, ctypes.byref(nl_mask)), "DDP: model structure")
+        if (nl_mask.value >> n) == 0:
+            f_ux = f_uu = None
+        else:
+            f_ux = torch.empty((B, N, n, m, n), dtype=dt, device=dev)
+            f_uu = torch.empty((B, N, n, m, m), dtype=dt, device=dev)
+        p_ux = f_ux.data_ptr() if f_ux is not None else None
+        p_uu = f_uu.data_ptr() if f_uu is not None else None
     converged = torch.zeros(B, dtype=torch.int32, device=dev)
     active = torch.ones(B, dtype=torch.int32, device=dev)
     it = 0
@@ -421,9 +429,9 @@ def _ilqr_or_ddp(dynamics, runningCost, terminalCost, x0, uGuess, maxIter, tol, 
                    "iterativeLqr: quadratize")
         if ddp:
             _lib.check(lib.zm_quadratic_dynamics_f64(pmd, xT.data_ptr(), uT.data_ptr(), ap, f_xx.data_ptr(),
-                                                     f_ux.data_ptr(), f_uu.data_ptr(), B, N, st), "DDP: quadratic dynamics")
-            _lib.check(lib.zm_ddp_backward_f64(f_x.data_ptr(), f_u.data_ptr(), f_xx.data_ptr(), f_ux.data_ptr(),
-                                               f_uu.data_ptr(), c_x.data_ptr(), c_u.data_ptr(), c_xx.data_ptr(),
+                                                     p_ux, p_uu, B, N, st), "DDP: quadratic dynamics")
+            _lib.check(lib.zm_ddp_backward_f64(f_x.data_ptr(), f_u.data_ptr(), f_xx.data_ptr(), p_ux,
+                                               p_uu, c_x.data_ptr(), c_u.data_ptr(), c_xx.data_ptr(),
                                                c_ux.data_ptr(), c_uu.data_ptr(), v_x.data_ptr(), v_xx.data_ptr(), ap, 1,
                                                l.data_ptr(), L.data_ptr(), B, N, n, m, st), "DDP: backward pass")
         else:
