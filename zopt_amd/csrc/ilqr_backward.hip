@@ -235,12 +235,11 @@ __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double S[4][4], b[4], x[4], qu[4];
+    double S[4][4], b[4], x[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) S[i][jj] = sm[i * 16 + NP + jj];
-        qu[i] = sm[64 + NP + i];  // Q_u (zero beyond m)
     }
     b[0] = sm[ob0];
     b[1] = sm[ob1];
@@ -257,6 +256,12 @@ __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], 
     if (a.vOut) *a.pOut = out;
     a.pOut -= a.sOut;
     const double lv = a.vL ? out : 0.0;
+    // Q_u (zero beyond m) is read only now: eight registers fewer across the solve; its LDS row is rewritten in the next step
+    double qu[4];
+    if constexpr (MODE != 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qu[i] = sm[64 + NP + i];
+    }
     if constexpr (MODE != 1) {
         // -1/2 l^T Q_uu l with l = -x, Q_uu x = Q_u  (ilqrUtils.py:170 / :203), on the lanes that solved for l
         if (c == NP) a.vsum -= 0.5 * ((x[0] * qu[0] + x[1] * qu[1]) + (x[2] * qu[2] + x[3] * qu[3]));
