@@ -37,3 +37,18 @@ def test_rejects_incomplete_or_foreign_files(tmp_path):
     np.savez(tmp_path / "foreign.npz", a=np.eye(2))
     with pytest.raises(ValueError):
         zio.load(tmp_path / "foreign.npz")
+
+
+def test_interpMapped_matches_componentwise_numpy_interp():
+    """zopt.jaxUtils.interpMapped (jaxUtils.py:7-24): jnp.interp per row of fp, clipped ends by default."""
+    import numpy as np
+    from zopt_amd import jaxUtils
+    xp = np.linspace(0.0, 2.0, 5)
+    fp = np.stack([xp ** 2, -xp, np.ones_like(xp)])
+    out = jaxUtils.interpMapped(0.75, xp, fp)
+    assert out.shape == (3,)
+    assert np.allclose(out, [0.5 * (0.25 + 1.0), -0.75, 1.0])
+    assert np.allclose(jaxUtils.interpMapped(-1.0, xp, fp), fp[:, 0]) and np.allclose(jaxUtils.interpMapped(9.0, xp, fp), fp[:, -1])
+    assert jaxUtils.interpMapped(np.array([0.1, 0.2]), xp, fp).shape == (3, 2)
+    f = lambda a: a
+    assert jaxUtils.maybeJit(f, True) is f and jaxUtils.maybeJitCls(f) is f
