@@ -99,6 +99,9 @@ def test_python_surface_mirrors_reference_signatures():
     for cls in (pytrees.AffineDynamics, pytrees.QuadraticDynamics, pytrees.QuadraticCostFunction):
         assert callable(cls.from_function) and callable(cls.from_trajectory)
     assert callable(pytrees.QuadraticValueFunction.fromTerminalCostFunction)
+    from zopt_amd import quadcopter
+    for name in ("trim", "linearize", "rigidBodyDynamics", "inertialDynamics"):                       # quadcopter.py:70-201
+        assert callable(getattr(quadcopter.Quadcopter, name))
 
 
 def test_product_never_imports_oracle():

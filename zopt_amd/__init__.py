@@ -8,5 +8,5 @@ no CPU fallback -- if the HIP library or a GPU is missing the calls raise.
 """
 from . import _lib  # noqa: F401
 
-__all__ = ["lqrUtils", "ilqrUtils", "mpcUtils", "pytrees", "models", "simulator", "jaxUtils", "dist", "io"]
+__all__ = ["lqrUtils", "ilqrUtils", "mpcUtils", "pytrees", "models", "quadcopter", "simulator", "jaxUtils", "dist", "io"]
 __version__ = "0.1.0"
