@@ -13,7 +13,9 @@ Rank 0 prints ONE JSON line (see README / DESIGN.md "Measurement").
 
 Defaults: 300 timed steps after 50 warm-up steps (56 ms of GPU time).  A step is 0.15 ms, and this GPU needs tens of
 milliseconds under load to leave its idle clock state (measured: 10 warm-up + 50 timed steps -> 174 us per launch,
-50 + 300 -> 147 us), so short runs mostly time the clock ramp.
+50 + 300 -> 147 us), so short runs mostly time the clock ramp.  To make the line independent of the K / W a caller
+picks, an untimed device warm-up (--prewarm-ms, default 60 ms of launches) precedes the W warm-up steps; the timed
+region is still exactly K steps between barrier + synchronize.
 """
 import argparse
 import json
@@ -99,6 +101,9 @@ def main():
     ap.add_argument("--n", type=int, default=12)
     ap.add_argument("--m", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prewarm-ms", type=float, default=60.0,
+                    help="untimed device warm-up before the W warm-up steps: launches until this much time has passed, so that a "
+                         "run with small --warmup/--steps is not a measurement of the clock ramp (0 disables)")
     ap.add_argument("--gather", action="store_true", help="(default for N > 1) also time an RCCL all-gather of the gains, reported separately")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the all-gather of the results after the timed region")
     args = ap.parse_args()
@@ -136,6 +141,12 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if args.prewarm_ms > 0:      # leave the idle clock state (docstring); not part of the W warm-up steps or of the timed region
+        p0 = time.perf_counter()
+        while (time.perf_counter() - p0) * 1e3 < args.prewarm_ms:
+            for i in range(16):
+                step(i)
+            torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
