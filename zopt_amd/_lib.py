@@ -93,7 +93,7 @@ _lib = None
 
 def build(verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 in-tree (``make -C zopt_amd/csrc``)."""
-    out = subprocess.run(["make", "-C", CSRC], capture_output=True, text=True)
+    out = subprocess.run(["make", "-C", CSRC, f"-j{max(1, min(8, os.cpu_count() or 1))}"], capture_output=True, text=True)
     if verbose or out.returncode != 0:
         print(out.stdout)
         print(out.stderr)
