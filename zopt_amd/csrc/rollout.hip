@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64) void rollout_linesearch_kernel(const zm_model_t
 // rollout_fast.hip: compile-time (n, m) = (12, 4), 16 step sizes
 int rollout_fast_dispatch(const zm_model_t& md, const double* Q, const double* R, const double* Qf, int diagonal, const double* x0,
                           const double* l, const double* L, const double* xPrev, const double* uPrev,
-                          const double* alphas, const int* active, const int* list, int64_t count, double* xTraj,
+                          const double* alphas, int n_alpha, const int* active, const int* list, int64_t count, double* xTraj,
                           double* uTraj, double* J, int* idx, int64_t batch, int T, hipStream_t st);
 
 }  // namespace zm
@@ -178,8 +178,10 @@ static int rollout_impl(const zm_model_t* model, const zm_quadcost_t* cost, cons
         return e && e[0] == 'g';
     }();
     const bool windy = md.wind_ned[0] != 0.0 || md.wind_ned[1] != 0.0 || md.wind_ned[2] != 0.0;   // fast path: still air only
-    if (!force_generic && !windy && n_alpha == 16 && md.n == 12 && md.m == 4 && cost && T >= 1)
-        return zm::rollout_fast_dispatch(md, cs.Q, cs.R, cs.Qf, cs.diagonal, x0, l, L, xPrev, uPrev, alphas, act, (const int*)list, count, xTraj,
+    // (one step size -- the solvers' initial rollout -- runs the same kernel with all 16 lanes of a group on that step size: 16x
+    //  redundant, and still several times faster than the generic lane-per-trajectory kernel with its uncoalesced policy reads)
+    if (!force_generic && !windy && (n_alpha == 16 || n_alpha == 1) && md.n == 12 && md.m == 4 && cost && T >= 1)
+        return zm::rollout_fast_dispatch(md, cs.Q, cs.R, cs.Qf, cs.diagonal, x0, l, L, xPrev, uPrev, alphas, n_alpha, act, (const int*)list, count, xTraj,
                                          uTraj, J, (int*)alpha_idx, batch, T, st);
     if (n_alpha == 1) {
         const unsigned blocks = (unsigned)((nslot + 63) / 64);

@@ -38,6 +38,7 @@ struct FastArgs {
     int* idx;
     long batch;
     int T;
+    int n_alpha;       // 16, or 1: every lane of a trajectory's group rolls the same step size (lane 0 stores; no second pass)
 };
 
 template <int KIND>
@@ -131,7 +132,7 @@ __device__ __forceinline__ void rollout_ls_body(const FastArgs& g, const double*
     const bool live = (slot < nslot) && (g.active == nullptr || g.active[traj] != 0);
     const long t = live ? traj : 0;
     const int T = g.T;
-    const double alpha = g.alphas[a];
+    const double alpha = g.alphas[g.n_alpha == 1 ? 0 : a];
 
     PolPtrs pp;
     {
@@ -315,10 +316,10 @@ static int launch_fast(const FastArgs& g, const bool diag_only, hipStream_t st) 
 // Fast path dispatch: (n, m) = (12, 4), 16 step sizes.
 int rollout_fast_dispatch(const zm_model_t& md, const double* Q, const double* R, const double* Qf, int diagonal,
                           const double* x0, const double* l, const double* L, const double* xPrev, const double* uPrev,
-                          const double* alphas, const int* active, const int* list, int64_t count, double* xTraj,
+                          const double* alphas, int n_alpha, const int* active, const int* list, int64_t count, double* xTraj,
                           double* uTraj, double* J, int* idx, int64_t batch, int T, hipStream_t st) {
     FastArgs g{md.A, md.B, md.dt, Q, R, Qf, x0, l, L, xPrev, uPrev, alphas, active, list, (long)count, xTraj, uTraj, J, idx,
-               (long)batch, T};
+               (long)batch, T, n_alpha};
     if (md.kind == ZM_MODEL_QUADCOPTER) return launch_fast<ZM_MODEL_QUADCOPTER>(g, diagonal == 1, st);
     return launch_fast<ZM_MODEL_LINEAR>(g, diagonal == 1, st);
 }
