@@ -235,6 +235,20 @@ int zm_riccati_value_f64(const double* f_x, const double* f_u, const double* f_x
                          const double* c_uu, const double* vf, const double* vf_x, const double* vf_xx, double* l, double* L,
                          double* v_out, double* vx_out, double* vxx_out, int64_t batch, int T, int n, int m, void* stream);
 
+/* The three expansions over a compacted list of trajectory ids (as zm_rollout_linesearch_list_f64): only list[0..count) are expanded
+ * -- the grids shrink with the list -- all arrays keep their full (batch, ...) shapes and are indexed by trajectory id; listed
+ * trajectories with active == 0 are skipped.  list == NULL: every trajectory, i.e. the plain entry points below / above. */
+int zm_linearize_dynamics_list_f64(const zm_model_t* model, const double* xTraj, const double* uTraj, const int32_t* list,
+                                   int64_t count, const int32_t* active, double* f, double* f_x, double* f_u, int64_t batch, int T,
+                                   void* stream);
+int zm_quadratize_cost_list_f64(const zm_quadcost_t* cost, int n, int m, const double* xTraj, const double* uTraj,
+                                const int32_t* list, int64_t count, const int32_t* active, double* c, double* c_x, double* c_u,
+                                double* v, double* v_x, double* c_xx, double* c_ux, double* c_uu, double* v_xx, int64_t batch,
+                                int T, void* stream);
+int zm_quadratic_dynamics_list_f64(const zm_model_t* model, const double* xTraj, const double* uTraj, const int32_t* list,
+                                   int64_t count, const int32_t* active, double* f_xx, double* f_ux, double* f_uu, int64_t batch,
+                                   int T, void* stream);
+
 /* Variables in which a registered model is NOT affine: bit i = state i, bit n + j = control j.  Only pairs of these have a nonzero
  * second derivative -- the second-order expansion evaluates only those pairs, and a driver need not materialise the zero blocks. */
 int zm_model_nonlinear_mask(const zm_model_t* model, uint32_t* mask);

@@ -334,3 +334,50 @@ def test_iterativeLqr_baseline_config4_full_size(mods):
     assert np.array_equal(cs, conv[sub])
     assert np.array_equal(Js, J[sub], equal_nan=True)
     assert np.array_equal(ts.uTraj, traj.uTraj[sub], equal_nan=True) and np.array_equal(Ls, L[sub], equal_nan=True)
+
+
+def test_expansions_over_an_id_list_match_the_full_calls(mods):
+    """zm_linearize_dynamics_list_f64 / zm_quadratize_cost_list_f64 / zm_quadratic_dynamics_list_f64: the listed trajectories get
+    bit for bit what the plain entry points write, every other trajectory is left untouched, listed-but-inactive ones are skipped,
+    an empty list is a no-op."""
+    import ctypes
+    import torch
+    _, models, _, _lib = mods
+    lib = _lib.lib()
+    rng = np.random.default_rng(12)
+    B, N, n, m = 11, 7, 12, 4
+    xT = torch.as_tensor(0.4 * rng.standard_normal((B, N + 1, n)), device="cuda")
+    uT = torch.as_tensor(np.array([9.807, 0, 0, 0]) + 0.5 * rng.standard_normal((B, N, m)), device="cuda")
+    md = models.QuadcopterEuler(0.1).c_struct()
+    cs = models.QuadraticCost(np.eye(n) + 0.1 * np.ones((n, n)), np.eye(m), 10 * np.eye(n)).c_struct()
+    pm, pc = ctypes.addressof(md), ctypes.addressof(cs)
+    ids = torch.tensor([9, 2, 5, 0], dtype=torch.int32, device="cuda")
+    act = torch.ones(B, dtype=torch.int32, device="cuda")
+    act[5] = 0
+    mk = lambda *s: torch.full(s, 7.0, dtype=torch.float64, device="cuda")
+    shapes = {"f_x": (B, N, n, n), "f_u": (B, N, n, m), "c_x": (B, N, n), "c_u": (B, N, m), "v_x": (B, n), "c": (B, N),
+              "f_xx": (B, N, n, n, n), "f_ux": (B, N, n, m, n), "f_uu": (B, N, n, m, m)}
+    full = {k: mk(*s) for k, s in shapes.items()}
+    part = {k: mk(*s) for k, s in shapes.items()}
+    p = lambda t: t.data_ptr()
+    assert lib.zm_linearize_dynamics_f64(pm, p(xT), p(uT), None, None, p(full["f_x"]), p(full["f_u"]), B, N, None) == 0
+    assert lib.zm_quadratize_cost_f64(pc, n, m, p(xT), p(uT), None, p(full["c"]), p(full["c_x"]), p(full["c_u"]), None, p(full["v_x"]),
+                                      None, None, None, None, B, N, None) == 0
+    assert lib.zm_quadratic_dynamics_f64(pm, p(xT), p(uT), None, p(full["f_xx"]), p(full["f_ux"]), p(full["f_uu"]), B, N, None) == 0
+    for cnt in (0, int(ids.numel())):
+        assert lib.zm_linearize_dynamics_list_f64(pm, p(xT), p(uT), p(ids), cnt, p(act), None, p(part["f_x"]), p(part["f_u"]),
+                                                  B, N, None) == 0
+        assert lib.zm_quadratize_cost_list_f64(pc, n, m, p(xT), p(uT), p(ids), cnt, p(act), p(part["c"]), p(part["c_x"]),
+                                               p(part["c_u"]), None, p(part["v_x"]), None, None, None, None, B, N, None) == 0
+        assert lib.zm_quadratic_dynamics_list_f64(pm, p(xT), p(uT), p(ids), cnt, p(act), p(part["f_xx"]), p(part["f_ux"]),
+                                                  p(part["f_uu"]), B, N, None) == 0
+        torch.cuda.synchronize()
+        done = [9, 2, 0] if cnt else []
+        for k in shapes:
+            for b in range(B):
+                if b in done:
+                    assert torch.equal(part[k][b], full[k][b]), (k, b)
+                else:
+                    assert bool((part[k][b] == 7.0).all()), (k, b)
+    assert lib.zm_linearize_dynamics_list_f64(pm, p(xT), p(uT), p(ids), B + 1, None, None, p(part["f_x"]), p(part["f_u"]),
+                                              B, N, None) == _lib.ZM_EINVAL

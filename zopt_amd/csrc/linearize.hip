@@ -18,15 +18,18 @@ __global__ __launch_bounds__(64) void linearize_dynamics_kernel(const zm_model_t
                                                                 const double* __restrict__ uTraj,
                                                                 const int* __restrict__ active, double* __restrict__ f,
                                                                 double* __restrict__ f_x, double* __restrict__ f_u,
-                                                                const long batch, const int T) {
+                                                                const long batch, const int T,
+                                                                const int* __restrict__ list, const long count) {
     const int lane = threadIdx.x;
     const int j = lane & 15;                                   // seed direction / Jacobian column
-    const long pt = (long)blockIdx.x * 4 + (lane >> 4);        // point index = traj * T + k
-    const long npts = batch * T;
-    if (pt >= npts) return;
-    const long traj = pt / T;
-    const int k = (int)(pt - traj * T);
+    const long sp = (long)blockIdx.x * 4 + (lane >> 4);        // slot * T + k; slots are the listed trajectories, or all of them
+    const long nslot = list ? count : batch;
+    if (sp >= nslot * T) return;
+    const long slot = sp / T;
+    const int k = (int)(sp - slot * T);
+    const long traj = list ? (long)list[slot] : slot;
     if (active && active[traj] == 0) return;
+    const long pt = traj * T + k;                              // point index
     const int n = md.n, m = md.m;
     if (j >= n + m) return;
     const double* xk = xTraj + (traj * (T + 1) + k) * n;
@@ -61,11 +64,13 @@ __global__ __launch_bounds__(64) void quadratic_dynamics_kernel(const zm_model_t
                                                                 const double* __restrict__ uTraj,
                                                                 const int* __restrict__ active, double* __restrict__ f_xx,
                                                                 double* __restrict__ f_ux, double* __restrict__ f_uu,
-                                                                const long batch, const int T) {
-    const long pt = blockIdx.x;
-    const long traj = pt / T;
-    const int k = (int)(pt - traj * T);
+                                                                const long batch, const int T, const int* __restrict__ list,
+                                                                const long count) {
+    const long slot = blockIdx.x / T;
+    const int k = (int)(blockIdx.x - slot * T);
+    const long traj = list ? (long)list[slot] : slot;
     if (active && active[traj] == 0) return;
+    const long pt = traj * T + k;
     const int n = md.n, m = md.m, K = n + m;
     const double* xk = xTraj + (traj * (T + 1) + k) * n;
     const double* uk = uTraj + pt * m;
@@ -134,14 +139,18 @@ __global__ __launch_bounds__(256) void quadratize_cost_kernel(const zm_quadcost_
                                                               const int* __restrict__ active, double* __restrict__ c,
                                                               double* __restrict__ c_x, double* __restrict__ c_u,
                                                               double* __restrict__ v, double* __restrict__ v_x,
-                                                              const long batch, const int T) {
-    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long npts = batch * T;
-    if (id >= npts + batch) return;
-    const bool terminal = id >= npts;
-    const long traj = terminal ? (id - npts) : (id / T);
+                                                              const long batch, const int T, const int* __restrict__ list,
+                                                              const long count) {
+    const long sid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long nslot = list ? count : batch;
+    const long npts = nslot * T;
+    if (sid >= npts + nslot) return;
+    const bool terminal = sid >= npts;
+    const long slot = terminal ? (sid - npts) : (sid / T);
+    const long traj = list ? (long)list[slot] : slot;
     if (active && active[traj] == 0) return;
-    const int k = terminal ? T : (int)(id - traj * T);
+    const int k = terminal ? T : (int)(sid - slot * T);
+    const long id = traj * T + k;                              // point index (unused for the terminal expansion)
     const double* xk = xTraj + (traj * (T + 1) + k) * n;
     double x[MAXN], u[MAXM];
 #pragma unroll
@@ -219,19 +228,55 @@ static int zm_check_model(const zm_model_t* model, zm_model_t& md, const char* w
     return ZM_OK;
 }
 
-extern "C" int zm_linearize_dynamics_f64(const zm_model_t* model, const double* xTraj, const double* uTraj,
-                                         const int32_t* active, double* f, double* f_x, double* f_u, int64_t batch, int T,
-                                         void* stream) {
-    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
+// list == NULL: every trajectory (subject to `active`); else the `count` listed ones -- the grid shrinks with the list
+static int zm_check_list(const char* who, const int32_t* list, int64_t count, int64_t batch) {
+    if (list && (count < 0 || count > batch)) return zm::set_error(ZM_EINVAL, "%s: bad list length", who);
+    return ZM_OK;
+}
+
+extern "C" int zm_linearize_dynamics_list_f64(const zm_model_t* model, const double* xTraj, const double* uTraj,
+                                              const int32_t* list, int64_t count, const int32_t* active, double* f,
+                                              double* f_x, double* f_u, int64_t batch, int T, void* stream) {
+    if (batch == 0 || (list && count == 0)) return ZM_OK;   /* nothing to do (pointers of empty arrays may be NULL) */
     zm_model_t md;
     int rc = zm_check_model(model, md, "zm_linearize_dynamics_f64");
     if (rc) return rc;
     if (!xTraj || !uTraj || !f_x || !f_u) return zm::set_error(ZM_EINVAL, "zm_linearize_dynamics_f64: null pointer");
     if (batch < 0 || T < 1) return zm::set_error(ZM_EINVAL, "zm_linearize_dynamics_f64: bad size");
-    if (batch == 0) return ZM_OK;
-    const long npts = (long)batch * T;
+    if ((rc = zm_check_list("zm_linearize_dynamics_list_f64", list, count, batch))) return rc;
+    const long npts = (long)(list ? count : batch) * T;
     hipLaunchKernelGGL(zm::linearize_dynamics_kernel, dim3((unsigned)((npts + 3) / 4)), dim3(64), 0, (hipStream_t)stream, md,
-                       xTraj, uTraj, (const int*)active, f, f_x, f_u, (long)batch, T);
+                       xTraj, uTraj, (const int*)active, f, f_x, f_u, (long)batch, T, (const int*)list, (long)count);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+
+extern "C" int zm_linearize_dynamics_f64(const zm_model_t* model, const double* xTraj, const double* uTraj,
+                                         const int32_t* active, double* f, double* f_x, double* f_u, int64_t batch, int T,
+                                         void* stream) {
+    return zm_linearize_dynamics_list_f64(model, xTraj, uTraj, nullptr, 0, active, f, f_x, f_u, batch, T, stream);
+}
+
+extern "C" int zm_quadratize_cost_list_f64(const zm_quadcost_t* cost, int n, int m, const double* xTraj, const double* uTraj,
+                                           const int32_t* list, int64_t count, const int32_t* active, double* c, double* c_x,
+                                           double* c_u, double* v, double* v_x, double* c_xx, double* c_ux, double* c_uu,
+                                           double* v_xx, int64_t batch, int T, void* stream) {
+    /* batch == 0 is a valid call: it still writes the trajectory-independent Hessians (xTraj, uTraj may then be NULL) */
+    if (!cost || !cost->Q || !cost->R || !cost->Qf || (batch != 0 && (!xTraj || !uTraj)))
+        return zm::set_error(ZM_EINVAL, "zm_quadratize_cost_f64: null pointer");
+    if (n < 1 || n > zm::MAXN || m < 1 || m > zm::MAXM)
+        return zm::set_error(ZM_EUNSUPPORTED, "zm_quadratize_cost_f64: (n=%d, m=%d) not covered", n, m);
+    if (batch < 0 || T < 1) return zm::set_error(ZM_EINVAL, "zm_quadratize_cost_f64: bad size");
+    if (const int rcl = zm_check_list("zm_quadratize_cost_list_f64", list, count, batch)) return rcl;
+    hipStream_t st = (hipStream_t)stream;
+    if (c_xx || c_ux || c_uu || v_xx)
+        hipLaunchKernelGGL(zm::cost_hessians_kernel, dim3(1), dim3(256), 0, st, *cost, n, m, c_xx, c_ux, c_uu, v_xx);
+    const long nslot = list ? (long)count : (long)batch;
+    if (nslot > 0 && (c || c_x || c_u || v || v_x)) {
+        const long work = nslot * T + nslot;
+        hipLaunchKernelGGL(zm::quadratize_cost_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, *cost, n, m,
+                           xTraj, uTraj, (const int*)active, c, c_x, c_u, v, v_x, (long)batch, T, (const int*)list, (long)count);
+    }
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }
@@ -240,28 +285,14 @@ extern "C" int zm_quadratize_cost_f64(const zm_quadcost_t* cost, int n, int m, c
                                       const int32_t* active, double* c, double* c_x, double* c_u, double* v, double* v_x,
                                       double* c_xx, double* c_ux, double* c_uu, double* v_xx, int64_t batch, int T,
                                       void* stream) {
-    /* batch == 0 is a valid call: it still writes the trajectory-independent Hessians (xTraj, uTraj may then be NULL) */
-    if (!cost || !cost->Q || !cost->R || !cost->Qf || (batch != 0 && (!xTraj || !uTraj)))
-        return zm::set_error(ZM_EINVAL, "zm_quadratize_cost_f64: null pointer");
-    if (n < 1 || n > zm::MAXN || m < 1 || m > zm::MAXM)
-        return zm::set_error(ZM_EUNSUPPORTED, "zm_quadratize_cost_f64: (n=%d, m=%d) not covered", n, m);
-    if (batch < 0 || T < 1) return zm::set_error(ZM_EINVAL, "zm_quadratize_cost_f64: bad size");
-    hipStream_t st = (hipStream_t)stream;
-    if (c_xx || c_ux || c_uu || v_xx)
-        hipLaunchKernelGGL(zm::cost_hessians_kernel, dim3(1), dim3(256), 0, st, *cost, n, m, c_xx, c_ux, c_uu, v_xx);
-    if (batch > 0 && (c || c_x || c_u || v || v_x)) {
-        const long work = (long)batch * T + batch;
-        hipLaunchKernelGGL(zm::quadratize_cost_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, *cost, n, m,
-                           xTraj, uTraj, (const int*)active, c, c_x, c_u, v, v_x, (long)batch, T);
-    }
-    ZM_HIP_CHECK(hipGetLastError());
-    return ZM_OK;
+    return zm_quadratize_cost_list_f64(cost, n, m, xTraj, uTraj, nullptr, 0, active, c, c_x, c_u, v, v_x, c_xx, c_ux, c_uu, v_xx,
+                                       batch, T, stream);
 }
 
-extern "C" int zm_quadratic_dynamics_f64(const zm_model_t* model, const double* xTraj, const double* uTraj,
-                                         const int32_t* active, double* f_xx, double* f_ux, double* f_uu, int64_t batch,
-                                         int T, void* stream) {
-    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
+extern "C" int zm_quadratic_dynamics_list_f64(const zm_model_t* model, const double* xTraj, const double* uTraj,
+                                              const int32_t* list, int64_t count, const int32_t* active, double* f_xx,
+                                              double* f_ux, double* f_uu, int64_t batch, int T, void* stream) {
+    if (batch == 0 || (list && count == 0)) return ZM_OK;   /* nothing to do (pointers of empty arrays may be NULL) */
     zm_model_t md;
     int rc = zm_check_model(model, md, "zm_quadratic_dynamics_f64");
     if (rc) return rc;
@@ -270,11 +301,18 @@ extern "C" int zm_quadratic_dynamics_f64(const zm_model_t* model, const double* 
         return zm::set_error(ZM_EINVAL, "zm_quadratic_dynamics_f64: f_ux / f_uu may only be omitted for a model that is affine in its "
                                         "controls (zm_model_nonlinear_mask)");
     if (batch < 0 || T < 1) return zm::set_error(ZM_EINVAL, "zm_quadratic_dynamics_f64: bad size");
-    if (batch == 0) return ZM_OK;
-    hipLaunchKernelGGL(zm::quadratic_dynamics_kernel, dim3((unsigned)(batch * T)), dim3(64), 0, (hipStream_t)stream, md, xTraj,
-                       uTraj, (const int*)active, f_xx, f_ux, f_uu, (long)batch, T);
+    if ((rc = zm_check_list("zm_quadratic_dynamics_list_f64", list, count, batch))) return rc;
+    const long nslot = list ? (long)count : (long)batch;
+    hipLaunchKernelGGL(zm::quadratic_dynamics_kernel, dim3((unsigned)(nslot * T)), dim3(64), 0, (hipStream_t)stream, md, xTraj,
+                       uTraj, (const int*)active, f_xx, f_ux, f_uu, (long)batch, T, (const int*)list, (long)count);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
+}
+
+extern "C" int zm_quadratic_dynamics_f64(const zm_model_t* model, const double* xTraj, const double* uTraj,
+                                         const int32_t* active, double* f_xx, double* f_ux, double* f_uu, int64_t batch,
+                                         int T, void* stream) {
+    return zm_quadratic_dynamics_list_f64(model, xTraj, uTraj, nullptr, 0, active, f_xx, f_ux, f_uu, batch, T, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

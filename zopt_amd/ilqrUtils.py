@@ -425,14 +425,17 @@ def _ilqr_or_ddp(dynamics, runningCost, terminalCost, x0, uGuess, maxIter, tol, 
                 break
             ids = torch.nonzero(active).flatten().to(torch.int32)
         ap = active.data_ptr()
-        _lib.check(lib.zm_linearize_dynamics_f64(pmd, xT.data_ptr(), uT.data_ptr(), ap, None, f_x.data_ptr(),
-                                                 f_u.data_ptr(), B, N, st), "iterativeLqr: linearize")
-        _lib.check(lib.zm_quadratize_cost_f64(pcs, n, m, xT.data_ptr(), uT.data_ptr(), ap, None, c_x.data_ptr(),
-                                              c_u.data_ptr(), None, v_x.data_ptr(), None, None, None, None, B, N, st),
+        # the expansions run over the compacted id list as the line search does: with a mask alone their grids would stay at the
+        # full batch (late iterations: ~100 us of early-exiting blocks per iteration)
+        ip, ic = ids.data_ptr(), int(ids.numel())
+        _lib.check(lib.zm_linearize_dynamics_list_f64(pmd, xT.data_ptr(), uT.data_ptr(), ip, ic, ap, None, f_x.data_ptr(),
+                                                      f_u.data_ptr(), B, N, st), "iterativeLqr: linearize")
+        _lib.check(lib.zm_quadratize_cost_list_f64(pcs, n, m, xT.data_ptr(), uT.data_ptr(), ip, ic, ap, None, c_x.data_ptr(),
+                                                   c_u.data_ptr(), None, v_x.data_ptr(), None, None, None, None, B, N, st),
                    "iterativeLqr: quadratize")
         if ddp:
-            _lib.check(lib.zm_quadratic_dynamics_f64(pmd, xT.data_ptr(), uT.data_ptr(), ap, f_xx.data_ptr(),
-                                                     p_ux, p_uu, B, N, st), "DDP: quadratic dynamics")
+            _lib.check(lib.zm_quadratic_dynamics_list_f64(pmd, xT.data_ptr(), uT.data_ptr(), ip, ic, ap, f_xx.data_ptr(),
+                                                          p_ux, p_uu, B, N, st), "DDP: quadratic dynamics")
             _lib.check(lib.zm_ddp_backward_f64(f_x.data_ptr(), f_u.data_ptr(), f_xx.data_ptr(), p_ux,
                                                p_uu, c_x.data_ptr(), c_u.data_ptr(), c_xx.data_ptr(),
                                                c_ux.data_ptr(), c_uu.data_ptr(), v_x.data_ptr(), v_xx.data_ptr(), ap, 1,
