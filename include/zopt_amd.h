@@ -235,6 +235,18 @@ int zm_riccati_value_f64(const double* f_x, const double* f_u, const double* f_x
                          const double* c_uu, const double* vf, const double* vf_x, const double* vf_xx, double* l, double* L,
                          double* v_out, double* vx_out, double* vxx_out, int64_t batch, int T, int n, int m, void* stream);
 
+/* zm_ilqr_backward_ex_f64 / zm_ddp_backward_f64 over a compacted list of trajectory ids: one wave per LISTED trajectory (grid =
+ * count), so that the few hundred stragglers of a solve spread over the whole chip instead of sharing SIMDs among 8192 mostly idle
+ * blocks.  Arrays keep their (batch, ...) shapes; listed trajectories with active == 0 are skipped; list == NULL: all of them. */
+int zm_ilqr_backward_list_f64(const double* f_x, const double* f_u, const double* c_x, const double* c_u, const double* c_xx,
+                              const double* c_ux, const double* c_uu, const double* vf_x, const double* vf_xx, const int32_t* list,
+                              int64_t count, const int32_t* active, int shared_hessian, double* l, double* L, int64_t batch, int T,
+                              int n, int m, void* stream);
+int zm_ddp_backward_list_f64(const double* f_x, const double* f_u, const double* f_xx, const double* f_ux, const double* f_uu,
+                             const double* c_x, const double* c_u, const double* c_xx, const double* c_ux, const double* c_uu,
+                             const double* vf_x, const double* vf_xx, const int32_t* list, int64_t count, const int32_t* active,
+                             int shared_hessian, double* l, double* L, int64_t batch, int T, int n, int m, void* stream);
+
 /* The three expansions over a compacted list of trajectory ids (as zm_rollout_linesearch_list_f64): only list[0..count) are expanded
  * -- the grids shrink with the list -- all arrays keep their full (batch, ...) shapes and are indexed by trajectory id; listed
  * trajectories with active == 0 are skipped.  list == NULL: every trajectory, i.e. the plain entry points below / above. */

@@ -209,3 +209,50 @@ def test_dma_ring_and_register_kernels_agree(n, T, shared):
         assert _rel(L[on], ref.L[on]) <= RTOL and _rel(l[on], ref.l[on]) <= RTOL
         outs.append((l, L))
     assert _rel(outs[0][1], outs[1][1]) <= 1e-12 and _rel(outs[0][0], outs[1][0]) <= 1e-12
+
+
+@pytest.mark.parametrize("n,ddp", [(12, False), (12, True), (5, False), (5, True)])
+def test_sweeps_over_an_id_list_match_the_full_calls(n, ddp):
+    """zm_ilqr_backward_list_f64 / zm_ddp_backward_list_f64 run one wave per LISTED trajectory: the listed ones get bit for bit
+    what the masked full-batch call writes (DMA-ring kernel at n = 12, register kernel at n = 5), the others keep their policy,
+    listed-but-inactive ones are skipped, an empty list is a no-op, an over-long list is rejected."""
+    import ctypes
+    import torch
+    from zopt_amd import _lib
+    lib = _lib.lib()
+    m, B, T = (4 if n == 12 else 3), 10, 9
+    dyn, cost, Vf = problems.random_ilqr_model(B, T, n, m, seed=50 + n)
+    rng = np.random.default_rng(n)
+    dev = [torch.as_tensor(np.ascontiguousarray(X), device="cuda") for X in (dyn[1], dyn[2], cost[1], cost[2], cost[3], cost[4], cost[5],
+                                                                             Vf[1], Vf[2])]
+    z = [torch.as_tensor(0.1 * rng.standard_normal(s), device="cuda") for s in ((B, T, n, n, n), (B, T, n, m, n), (B, T, n, m, m))]
+    z[0] = 0.5 * (z[0] + z[0].transpose(-1, -2)).contiguous()
+    z[2] = 0.5 * (z[2] + z[2].transpose(-1, -2)).contiguous()
+    p = lambda t: t.data_ptr()
+    ids = torch.tensor([7, 1, 4], dtype=torch.int32, device="cuda")
+    act = torch.ones(B, dtype=torch.int32, device="cuda")
+    act[4] = 0
+
+    def call(lst, cnt, a):
+        l = torch.full((B, T, m), 7.0, dtype=torch.float64, device="cuda")
+        L = torch.full((B, T, m, n), 7.0, dtype=torch.float64, device="cuda")
+        if ddp:
+            rc = lib.zm_ddp_backward_list_f64(p(dev[0]), p(dev[1]), p(z[0]), p(z[1]), p(z[2]), *[p(d) for d in dev[2:]],
+                                              lst, cnt, a, 0, p(l), p(L), B, T, n, m, None)
+        else:
+            rc = lib.zm_ilqr_backward_list_f64(*[p(d) for d in dev], lst, cnt, a, 0, p(l), p(L), B, T, n, m, None)
+        torch.cuda.synchronize()
+        return rc, l, L
+
+    rc, lf, Lf = call(None, 0, None)
+    assert rc == 0
+    for cnt in (0, 3):
+        rc, l, L = call(p(ids), cnt, p(act))
+        assert rc == 0
+        done = [7, 1] if cnt else []
+        for b in range(B):
+            if b in done:
+                assert torch.equal(l[b], lf[b]) and torch.equal(L[b], Lf[b])
+            else:
+                assert bool((l[b] == 7.0).all()) and bool((L[b] == 7.0).all())
+    assert call(p(ids), B + 1, None)[0] == _lib.ZM_EINVAL

@@ -77,6 +77,10 @@ SYMBOLS = {
                             [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     # (model*, xTraj, uTraj, active, f_xx, f_ux, f_uu, batch, T, stream)
     "zm_quadratic_dynamics_f64": (ctypes.c_int, [_c_dp] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "zm_ilqr_backward_list_f64": (ctypes.c_int, [_c_dp] * 10 + [ctypes.c_int64, _c_dp, ctypes.c_int] + [_c_dp] * 2 +
+                                  [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "zm_ddp_backward_list_f64": (ctypes.c_int, [_c_dp] * 13 + [ctypes.c_int64, _c_dp, ctypes.c_int] + [_c_dp] * 2 +
+                                 [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     # (model*, xTraj, uTraj, list, count, active, f, f_x, f_u, batch, T, stream)
     "zm_linearize_dynamics_list_f64": (ctypes.c_int, [_c_dp] * 4 + [ctypes.c_int64] + [_c_dp] * 4 +
                                        [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),

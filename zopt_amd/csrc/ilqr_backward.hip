@@ -55,6 +55,12 @@ struct IlqrStepRegs {
     double dr[KS];  // MODE 1: d[4s+g]    (row-indexed)
 };
 
+// optional compacted list of trajectory ids: block b works on list[b] (grid = count) instead of on trajectory b (grid = batch)
+struct TrajList {
+    const int* list;
+    long count;
+};
+
 template <int KS>
 struct IlqrAddr {
     const double* pF0;   // K-step s adds (rowok ? s*dF : 0)
@@ -306,10 +312,10 @@ __global__ __launch_bounds__(64, 2) void ilqr_backward_t16_f64(
     const double* __restrict__ f_uu, const long svx, const long svxx, const int* __restrict__ active,
     const int shared_h, double* __restrict__ lout, double* __restrict__ Lout, const int T, const int n, const int m,
     const double* __restrict__ c_s, const double* __restrict__ vf_s, double* __restrict__ v_out,
-    double* __restrict__ vx_out, double* __restrict__ vxx_out) {
+    double* __restrict__ vx_out, double* __restrict__ vxx_out, const TrajList tl) {
     constexpr int NP = 4 * KS;
     const int lane = threadIdx.x;
-    const long traj = blockIdx.x;
+    const long traj = tl.list ? (long)tl.list[blockIdx.x] : (long)blockIdx.x;
     if (active && active[traj] == 0) return;  // whole wave leaves: this trajectory keeps its previous policy
     const int g = lane >> 4, c = lane & 15;
     __shared__ double sm[ILQR_LDS_DOUBLES];
@@ -508,7 +514,7 @@ __global__ __launch_bounds__(64, 3) void ilqr_backward_dma_f64(
     const double* __restrict__ c_u, const double* __restrict__ c_xx, const double* __restrict__ c_ux,
     const double* __restrict__ c_uu, const double* __restrict__ vf_x, const double* __restrict__ vf_xx,
     const double* __restrict__ dvec, const long svx, const long svxx, const int* __restrict__ active,
-    double* __restrict__ lout, double* __restrict__ Lout, const int T) {
+    double* __restrict__ lout, double* __restrict__ Lout, const int T, const TrajList tl) {
     using G = IlqrDmaGeom<N, M, SHARED, MODE>;
     constexpr int KS = G::KS, NI = G::NI, SLOT = G::SLOT, NP = N;
     constexpr int nn = N * N, nm = N * M, mm = M * M;
@@ -516,7 +522,7 @@ __global__ __launch_bounds__(64, 3) void ilqr_backward_dma_f64(
     __shared__ __attribute__((aligned(16))) char lds[SMO + ILQR_LDS_DOUBLES * 8];
     double* sm = (double*)(lds + SMO);
     const int lane = threadIdx.x;
-    const long traj = blockIdx.x;
+    const long traj = tl.list ? (long)tl.list[blockIdx.x] : (long)blockIdx.x;
     if (active && active[traj] == 0) return;   // whole wave leaves: this trajectory keeps its previous policy
     const int g = lane >> 4, c = lane & 15;
     const bool cA = c < N, cB = (c >= N) && (c < N + M);
@@ -659,7 +665,8 @@ template <int MODE>
 static int ilqr_backward_dma_dispatch(const double* f_x, const double* f_u, const double* c_x, const double* c_u,
                                       const double* c_xx, const double* c_ux, const double* c_uu, const double* vf_x,
                                       const double* vf_xx, const double* dvec, long svx, long svxx, const int* act, int sh,
-                                      double* l, double* L, int64_t batch, int T, int n, int m, hipStream_t st) {
+                                      double* l, double* L, int64_t batch, int T, int n, int m, hipStream_t st,
+                                      TrajList tl = TrajList{nullptr, 0}) {
     static const bool off = [] {
         const char* e = getenv("ZOPT_AMD_ILQR_PATH");
         return e && e[0] == 'r';   // "reg": force the register-prefetch kernel
@@ -668,12 +675,12 @@ static int ilqr_backward_dma_dispatch(const double* f_x, const double* f_u, cons
     const uintptr_t al = (uintptr_t)f_x | (uintptr_t)f_u | (uintptr_t)c_x | (uintptr_t)c_u | (uintptr_t)dvec |
                          (sh ? 0 : ((uintptr_t)c_xx | (uintptr_t)c_ux | (uintptr_t)c_uu));
     if (al & 15) return ZM_EUNSUPPORTED;
-    const dim3 grid((unsigned)batch), block(64);
+    const dim3 grid((unsigned)(tl.list ? tl.count : batch)), block(64);
     // ring depth: 3 steps in flight when the step image is 2 KB (shared Hessians), 2 when it is 4 KB (measured: profiles/)
     constexpr int DS = 3, DF = 2;
 #define ZM_LAUNCH_ILQR_DMA(NN, DD, SH)                                                                                     \
     hipLaunchKernelGGL((ilqr_backward_dma_f64<NN, 4, DD, SH, MODE>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, \
-                       vf_x, vf_xx, dvec, svx, svxx, act, l, L, T)
+                       vf_x, vf_xx, dvec, svx, svxx, act, l, L, T, tl)
     if constexpr (MODE == 0) {
         if (n == 12) {
             if (sh) ZM_LAUNCH_ILQR_DMA(12, DS, true); else ZM_LAUNCH_ILQR_DMA(12, DF, false);
@@ -704,17 +711,17 @@ static int launch_ilqr(const double* f_x, const double* f_u, const double* c_x, 
                        const double* c_ux, const double* c_uu, const double* vf_x, const double* vf_xx, const double* d,
                        long svx, long svxx, const int* act, int sh, double* l, double* L, int64_t batch, int T, int n, int m,
                        hipStream_t st, DdpTensors z = DdpTensors{nullptr, nullptr, nullptr},
-                       ValueIO v = ValueIO{nullptr, nullptr, nullptr, nullptr, nullptr}) {
-    const dim3 grid((unsigned)batch), block(64);
+                       ValueIO v = ValueIO{nullptr, nullptr, nullptr, nullptr, nullptr}, TrajList tl = TrajList{nullptr, 0}) {
+    const dim3 grid((unsigned)(tl.list ? tl.count : batch)), block(64);
     if (n <= 4)
         hipLaunchKernelGGL((ilqr_backward_t16_f64<1, MODE>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
-                           vf_xx, d, z.f_xx, z.f_ux, z.f_uu, svx, svxx, act, sh, l, L, T, n, m, v.c, v.vf, v.v_out, v.vx_out, v.vxx_out);
+                           vf_xx, d, z.f_xx, z.f_ux, z.f_uu, svx, svxx, act, sh, l, L, T, n, m, v.c, v.vf, v.v_out, v.vx_out, v.vxx_out, tl);
     else if (n <= 8)
         hipLaunchKernelGGL((ilqr_backward_t16_f64<2, MODE>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
-                           vf_xx, d, z.f_xx, z.f_ux, z.f_uu, svx, svxx, act, sh, l, L, T, n, m, v.c, v.vf, v.v_out, v.vx_out, v.vxx_out);
+                           vf_xx, d, z.f_xx, z.f_ux, z.f_uu, svx, svxx, act, sh, l, L, T, n, m, v.c, v.vf, v.v_out, v.vx_out, v.vxx_out, tl);
     else
         hipLaunchKernelGGL((ilqr_backward_t16_f64<3, MODE>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
-                           vf_xx, d, z.f_xx, z.f_ux, z.f_uu, svx, svxx, act, sh, l, L, T, n, m, v.c, v.vf, v.v_out, v.vx_out, v.vxx_out);
+                           vf_xx, d, z.f_xx, z.f_ux, z.f_uu, svx, svxx, act, sh, l, L, T, n, m, v.c, v.vf, v.v_out, v.vx_out, v.vxx_out, tl);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }
@@ -729,21 +736,33 @@ static int zm_check_sweep_args(const char* who, int64_t batch, int T, int n, int
     return ZM_OK;
 }
 
-extern "C" int zm_ilqr_backward_ex_f64(const double* f_x, const double* f_u, const double* c_x, const double* c_u,
-                                       const double* c_xx, const double* c_ux, const double* c_uu, const double* vf_x,
-                                       const double* vf_xx, const int32_t* active, int shared_hessian, double* l,
-                                       double* L, int64_t batch, int T, int n, int m, void* stream) {
-    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
+extern "C" int zm_ilqr_backward_list_f64(const double* f_x, const double* f_u, const double* c_x, const double* c_u,
+                                         const double* c_xx, const double* c_ux, const double* c_uu, const double* vf_x,
+                                         const double* vf_xx, const int32_t* list, int64_t count, const int32_t* active,
+                                         int shared_hessian, double* l, double* L, int64_t batch, int T, int n, int m,
+                                         void* stream) {
+    if (batch == 0 || (list && count == 0)) return ZM_OK;   /* nothing to do (pointers of empty arrays may be NULL) */
+    if (list && (count < 0 || count > batch)) return zm::set_error(ZM_EINVAL, "zm_ilqr_backward_list_f64: bad list length");
+    const zm::TrajList tl{(const int*)list, (long)count};
     if (!f_x || !f_u || !c_x || !c_u || !c_xx || !c_ux || !c_uu || !vf_x || !vf_xx || !l || !L)
         return zm::set_error(ZM_EINVAL, "zm_ilqr_backward_f64: null pointer");
     const int rc = zm_check_sweep_args("zm_ilqr_backward_f64", batch, T, n, m);
     if (rc) return rc;
     if (zm::ilqr_backward_dma_dispatch<0>(f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, (long)n, (long)n * n,
                                        (const int*)active, shared_hessian ? 1 : 0, l, L, batch, T, n, m,
-                                       (hipStream_t)stream) == ZM_OK)
+                                       (hipStream_t)stream, tl) == ZM_OK)
         return ZM_OK;
     return zm::launch_ilqr<0>(f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, (long)n, (long)n * n,
-                              (const int*)active, shared_hessian ? 1 : 0, l, L, batch, T, n, m, (hipStream_t)stream);
+                              (const int*)active, shared_hessian ? 1 : 0, l, L, batch, T, n, m, (hipStream_t)stream,
+                              zm::DdpTensors{nullptr, nullptr, nullptr}, zm::ValueIO{nullptr, nullptr, nullptr, nullptr, nullptr}, tl);
+}
+
+extern "C" int zm_ilqr_backward_ex_f64(const double* f_x, const double* f_u, const double* c_x, const double* c_u,
+                                       const double* c_xx, const double* c_ux, const double* c_uu, const double* vf_x,
+                                       const double* vf_xx, const int32_t* active, int shared_hessian, double* l,
+                                       double* L, int64_t batch, int T, int n, int m, void* stream) {
+    return zm_ilqr_backward_list_f64(f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, 0, active, shared_hessian, l, L,
+                                     batch, T, n, m, stream);
 }
 
 extern "C" int zm_ilqr_backward_f64(const double* f_x, const double* f_u, const double* c_x, const double* c_u,
@@ -774,12 +793,13 @@ extern "C" int zm_lqr_backward_affine_f64(const double* A, const double* B, cons
                               n, m, (hipStream_t)stream);
 }
 
-extern "C" int zm_ddp_backward_f64(const double* f_x, const double* f_u, const double* f_xx, const double* f_ux,
-                                   const double* f_uu, const double* c_x, const double* c_u, const double* c_xx,
-                                   const double* c_ux, const double* c_uu, const double* vf_x, const double* vf_xx,
-                                   const int32_t* active, int shared_hessian, double* l, double* L, int64_t batch, int T,
-                                   int n, int m, void* stream) {
-    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
+extern "C" int zm_ddp_backward_list_f64(const double* f_x, const double* f_u, const double* f_xx, const double* f_ux,
+                                        const double* f_uu, const double* c_x, const double* c_u, const double* c_xx,
+                                        const double* c_ux, const double* c_uu, const double* vf_x, const double* vf_xx,
+                                        const int32_t* list, int64_t count, const int32_t* active, int shared_hessian,
+                                        double* l, double* L, int64_t batch, int T, int n, int m, void* stream) {
+    if (batch == 0 || (list && count == 0)) return ZM_OK;   /* nothing to do (pointers of empty arrays may be NULL) */
+    if (list && (count < 0 || count > batch)) return zm::set_error(ZM_EINVAL, "zm_ddp_backward_list_f64: bad list length");
     if (!f_x || !f_u || !f_xx || (!f_ux != !f_uu) || !c_x || !c_u || !c_xx || !c_ux || !c_uu || !vf_x || !vf_xx || !l || !L)
         return zm::set_error(ZM_EINVAL, "zm_ddp_backward_f64: null pointer (f_ux and f_uu may be NULL together: identically zero)");
     const int rc = zm_check_sweep_args("zm_ddp_backward_f64", batch, T, n, m);
@@ -788,7 +808,17 @@ extern "C" int zm_ddp_backward_f64(const double* f_x, const double* f_u, const d
     if (batch == 0) return ZM_OK;
     return zm::launch_ilqr<2>(f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, (long)n, (long)n * n,
                               (const int*)active, shared_hessian ? 1 : 0, l, L, batch, T, n, m, (hipStream_t)stream,
-                              zm::DdpTensors{f_xx, f_ux, f_uu});
+                              zm::DdpTensors{f_xx, f_ux, f_uu}, zm::ValueIO{nullptr, nullptr, nullptr, nullptr, nullptr},
+                              zm::TrajList{(const int*)list, (long)count});
+}
+
+extern "C" int zm_ddp_backward_f64(const double* f_x, const double* f_u, const double* f_xx, const double* f_ux,
+                                   const double* f_uu, const double* c_x, const double* c_u, const double* c_xx,
+                                   const double* c_ux, const double* c_uu, const double* vf_x, const double* vf_xx,
+                                   const int32_t* active, int shared_hessian, double* l, double* L, int64_t batch, int T,
+                                   int n, int m, void* stream) {
+    return zm_ddp_backward_list_f64(f_x, f_u, f_xx, f_ux, f_uu, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, 0, active,
+                                    shared_hessian, l, L, batch, T, n, m, stream);
 }
 
 extern "C" int zm_riccati_value_f64(const double* f_x, const double* f_u, const double* f_xx, const double* f_ux,

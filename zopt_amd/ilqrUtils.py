@@ -436,14 +436,14 @@ def _ilqr_or_ddp(dynamics, runningCost, terminalCost, x0, uGuess, maxIter, tol, 
         if ddp:
             _lib.check(lib.zm_quadratic_dynamics_list_f64(pmd, xT.data_ptr(), uT.data_ptr(), ip, ic, ap, f_xx.data_ptr(),
                                                           p_ux, p_uu, B, N, st), "DDP: quadratic dynamics")
-            _lib.check(lib.zm_ddp_backward_f64(f_x.data_ptr(), f_u.data_ptr(), f_xx.data_ptr(), p_ux,
-                                               p_uu, c_x.data_ptr(), c_u.data_ptr(), c_xx.data_ptr(),
-                                               c_ux.data_ptr(), c_uu.data_ptr(), v_x.data_ptr(), v_xx.data_ptr(), ap, 1,
-                                               l.data_ptr(), L.data_ptr(), B, N, n, m, st), "DDP: backward pass")
+            _lib.check(lib.zm_ddp_backward_list_f64(f_x.data_ptr(), f_u.data_ptr(), f_xx.data_ptr(), p_ux,
+                                                    p_uu, c_x.data_ptr(), c_u.data_ptr(), c_xx.data_ptr(),
+                                                    c_ux.data_ptr(), c_uu.data_ptr(), v_x.data_ptr(), v_xx.data_ptr(), ip, ic, ap, 1,
+                                                    l.data_ptr(), L.data_ptr(), B, N, n, m, st), "DDP: backward pass")
         else:
-            _lib.check(lib.zm_ilqr_backward_ex_f64(f_x.data_ptr(), f_u.data_ptr(), c_x.data_ptr(), c_u.data_ptr(),
-                                                   c_xx.data_ptr(), c_ux.data_ptr(), c_uu.data_ptr(), v_x.data_ptr(),
-                                                   v_xx.data_ptr(), ap, 1, l.data_ptr(), L.data_ptr(), B, N, n, m, st),
+            _lib.check(lib.zm_ilqr_backward_list_f64(f_x.data_ptr(), f_u.data_ptr(), c_x.data_ptr(), c_u.data_ptr(),
+                                                     c_xx.data_ptr(), c_ux.data_ptr(), c_uu.data_ptr(), v_x.data_ptr(),
+                                                     v_xx.data_ptr(), ip, ic, ap, 1, l.data_ptr(), L.data_ptr(), B, N, n, m, st),
                        "iterativeLqr: backward pass")
         # the 16-way line search packs 4 trajectories per wave: with a mask alone most waves would idle once most of the batch
         # has converged, so the still-active trajectories go in as a compacted id list (checked against the mask in the kernel)
