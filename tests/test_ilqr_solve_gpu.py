@@ -381,3 +381,34 @@ def test_expansions_over_an_id_list_match_the_full_calls(mods):
                     assert bool((part[k][b] == 7.0).all()), (k, b)
     assert lib.zm_linearize_dynamics_list_f64(pm, p(xT), p(uT), p(ids), B + 1, None, None, p(part["f_x"]), p(part["f_u"]),
                                               B, N, None) == _lib.ZM_EINVAL
+
+
+def test_quadratize_cost_diagonal_shortcut_is_exact(mods):
+    """With `zm_quadcost_t.diagonal = 1` the gradients c_x = (Q + Q^T) x, c_u, v_x skip the vanishing off-diagonal terms: bit for
+    bit the general formula (finite states), and equal to the oracle."""
+    import ctypes
+    import torch
+    _, models, _, _lib = mods
+    rng = np.random.default_rng(21)
+    b, N, n, m = 3, 5, 12, 4
+    Q, R, Qf = np.diag(rng.uniform(0.5, 2, n)), np.diag(rng.uniform(0.5, 2, m)), np.diag(rng.uniform(5, 20, n))
+    xT, uT = rng.standard_normal((b, N + 1, n)), rng.standard_normal((b, N, m))
+    dx, du = torch.as_tensor(xT, device="cuda"), torch.as_tensor(uT, device="cuda")
+    outs = []
+    cost = models.QuadraticCost(Q, R, Qf)       # keeps the device copies of Q, R, Qf alive: c_struct() only holds their addresses
+    for hint in (1, 0):
+        cs = cost.c_struct()
+        assert cs.diagonal == 1
+        cs.diagonal = hint
+        t = lambda *s: torch.empty(s, dtype=torch.float64, device="cuda")
+        c, c_x, c_u, v, v_x = t(b, N), t(b, N, n), t(b, N, m), t(b), t(b, n)
+        rc = _lib.lib().zm_quadratize_cost_f64(ctypes.addressof(cs), n, m, dx.data_ptr(), du.data_ptr(), None, c.data_ptr(),
+                                               c_x.data_ptr(), c_u.data_ptr(), v.data_ptr(), v_x.data_ptr(), None, None, None,
+                                               None, b, N, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        outs.append([a.cpu().numpy() for a in (c, c_x, c_u, v, v_x)])
+    for a, bb in zip(*outs):
+        assert np.array_equal(a, bb)
+    ref = zo.quadratic_cost_from_trajectory(Q, R, zo.Trajectory(xT[0], uT[0]))
+    assert _rel(outs[0][1][0], ref.c_x) <= 1e-13 and _rel(outs[0][2][0], ref.c_u) <= 1e-13

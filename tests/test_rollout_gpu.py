@@ -216,6 +216,7 @@ def test_diagonal_weight_kernels_agree(mods, kind):
         def c_struct(self):
             s = super().c_struct()
             s.diagonal = 0
+            assert s._owner is self        # the handle keeps the device copies of Q, R, Qf alive
             return s
 
     pol, prev = pt.AffinePolicy(l, L), pt.Trajectory(xPrev, uPrev)

@@ -158,14 +158,20 @@ __global__ __launch_bounds__(256) void quadratize_cost_kernel(const zm_quadcost_
     const double* Qm = terminal ? cs.Qf : cs.Q;
     double* gx = terminal ? (v_x ? v_x + traj * n : nullptr) : (c_x ? c_x + id * n : nullptr);
     if (gx) {
+        if (cs.diagonal == 1) {   // asserted diagonal weights: the n^2 - n vanishing terms of (Q + Q^T) x are not formed
 #pragma unroll
-        for (int jj = 0; jj < MAXN; ++jj) {
-            if (jj < n) {
-                double s = 0.0;   // ((Q + Q^T) x)[jj]
+            for (int jj = 0; jj < MAXN; ++jj)
+                if (jj < n) gx[jj] = (Qm[jj * n + jj] + Qm[jj * n + jj]) * x[jj];
+        } else {
 #pragma unroll
-                for (int i = 0; i < MAXN; ++i)
-                    if (i < n) s = __builtin_fma(Qm[jj * n + i] + Qm[i * n + jj], x[i], s);
-                gx[jj] = s;
+            for (int jj = 0; jj < MAXN; ++jj) {
+                if (jj < n) {
+                    double s = 0.0;   // ((Q + Q^T) x)[jj]
+#pragma unroll
+                    for (int i = 0; i < MAXN; ++i)
+                        if (i < n) s = __builtin_fma(Qm[jj * n + i] + Qm[i * n + jj], x[i], s);
+                    gx[jj] = s;
+                }
             }
         }
     }
@@ -177,14 +183,20 @@ __global__ __launch_bounds__(256) void quadratize_cost_kernel(const zm_quadcost_
 #pragma unroll
     for (int i = 0; i < MAXM; ++i) u[i] = (i < m) ? uk[i] : 0.0;
     if (c_u) {
+        if (cs.diagonal == 1) {
 #pragma unroll
-        for (int jj = 0; jj < MAXM; ++jj) {
-            if (jj < m) {
-                double s = 0.0;
+            for (int jj = 0; jj < MAXM; ++jj)
+                if (jj < m) c_u[id * m + jj] = (cs.R[jj * m + jj] + cs.R[jj * m + jj]) * u[jj];
+        } else {
 #pragma unroll
-                for (int i = 0; i < MAXM; ++i)
-                    if (i < m) s = __builtin_fma(cs.R[jj * m + i] + cs.R[i * m + jj], u[i], s);
-                c_u[id * m + jj] = s;
+            for (int jj = 0; jj < MAXM; ++jj) {
+                if (jj < m) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int i = 0; i < MAXM; ++i)
+                        if (i < m) s = __builtin_fma(cs.R[jj * m + i] + cs.R[i * m + jj], u[i], s);
+                    c_u[id * m + jj] = s;
+                }
             }
         }
     }

@@ -46,7 +46,9 @@ class LinearModel:
         import torch
         if self._dev is None:
             self._dev = (arr.to_device(self.A, torch.float64), arr.to_device(self.B, torch.float64))
-        return zm_model_t(ZM_MODEL_LINEAR, self.n, self.m, 0, 0.0, self._dev[0].data_ptr(), self._dev[1].data_ptr())
+        st = zm_model_t(ZM_MODEL_LINEAR, self.n, self.m, 0, 0.0, self._dev[0].data_ptr(), self._dev[1].data_ptr())
+        st._owner = self      # the struct holds raw device addresses: keep the arrays behind them alive with it
+        return st
 
 
 class QuadcopterEuler:
@@ -102,7 +104,9 @@ class QuadraticCost:
             self._dev = tuple(arr.to_device(X, torch.float64) for X in (self.Q, self.R, self.Qf))
         isdiag = lambda M: not np.any(M - np.diag(np.diagonal(M)))          # exact: also False for NaN off the diagonal
         diag = int(isdiag(self.Q) and isdiag(self.R) and isdiag(self.Qf))
-        return zm_quadcost_t(*[t.data_ptr() for t in self._dev], diag, 0)
+        st = zm_quadcost_t(*[t.data_ptr() for t in self._dev], diag, 0)
+        st._owner = self      # the struct holds raw device addresses: keep the arrays behind them alive with it
+        return st
 
 
 class QuadcopterRigidBody:
