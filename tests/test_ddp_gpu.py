@@ -190,3 +190,59 @@ def test_control_affine_models_skip_the_zero_blocks(mods):
                                                     f_uu[0].cpu().numpy()),
                                zo.QuadraticCostFunction(*[c[0] for c in cost]), zo.QuadraticValueFunction(*[v[0] for v in Vf]))
     assert _rel(outs[1][1][0], refp.L) <= 1e-9 and _rel(outs[1][0][0], refp.l) <= 1e-9
+
+
+@pytest.mark.parametrize("wind", [(0.0, 0.0, 0.0), (3.0, 1.0, -0.5)])
+def test_declared_hessian_pairs_cover_every_second_derivative(mods, wind):
+    """The quadcopter declares the 28 variable pairs that can have a second derivative (model_hessian_pairs, models.h); the kernel
+    evaluates only those, two trajectory points per wave.  Independent check, also with a constant wind (no autograd restatement
+    exists for it): central differences of the first-derivative kernel in all 16 variables reproduce every entry -- the declared
+    ones and the structural zeros."""
+    import ctypes
+    import torch
+    _, models, _, _lib = mods
+    lib = _lib.lib()
+    rng = np.random.default_rng(17)
+    n, m, N = 12, 4, 3
+    md = models.QuadcopterEuler(0.1, wind_ned=wind).c_struct()
+    pm = ctypes.addressof(md)
+    x = 0.6 * rng.standard_normal((1, N + 1, n))
+    u = np.array([9.807, 0, 0, 0]) + rng.standard_normal((1, N, m))
+    p = lambda t: t.data_ptr()
+
+    def jac(xa, ua):
+        dx, du = torch.as_tensor(xa, device="cuda"), torch.as_tensor(ua, device="cuda")
+        fx = torch.empty((1, N, n, n), dtype=torch.float64, device="cuda")
+        fu = torch.empty((1, N, n, m), dtype=torch.float64, device="cuda")
+        assert lib.zm_linearize_dynamics_f64(pm, p(dx), p(du), None, None, p(fx), p(fu), 1, N, None) == 0
+        torch.cuda.synchronize()
+        return np.concatenate([fx.cpu().numpy(), fu.cpu().numpy()], axis=-1)[0]          # (N, n, n + m)
+
+    dx, du = torch.as_tensor(x, device="cuda"), torch.as_tensor(u, device="cuda")
+    t = lambda *s: torch.full(s, float("nan"), dtype=torch.float64, device="cuda")
+    f_xx, f_ux, f_uu = t(1, N, n, n, n), t(1, N, n, m, n), t(1, N, n, m, m)
+    assert lib.zm_quadratic_dynamics_f64(pm, p(dx), p(du), None, p(f_xx), p(f_ux), p(f_uu), 1, N, None) == 0
+    torch.cuda.synchronize()
+    H = np.zeros((N, n, n + m, n + m))                         # H[k, i, a, b] = d2 f_i / dz_a dz_b from the kernel
+    H[:, :, :n, :n] = f_xx[0].cpu().numpy()
+    H[:, :, n:, :n] = f_ux[0].cpu().numpy()
+    H[:, :, :n, n:] = np.swapaxes(f_ux[0].cpu().numpy(), -1, -2)
+    H[:, :, n:, n:] = f_uu[0].cpu().numpy()
+    h = 1e-5
+    for j in range(n + m):
+        xp, xm_, up, um = x.copy(), x.copy(), u.copy(), u.copy()
+        if j < n:
+            xp[0, :N, j] += h
+            xm_[0, :N, j] -= h
+        else:
+            up[0, :, j - n] += h
+            um[0, :, j - n] -= h
+        fd = (jac(xp, up) - jac(xm_, um)) / (2 * h)           # (N, n, n + m): d/dz_j of the Jacobian
+        assert np.max(np.abs(fd - H[:, :, :, j])) <= 2e-8 * max(1.0, np.max(np.abs(H)))
+    assert np.max(np.abs(H)) > 1e-3
+    if any(wind):     # the wind really changes the curvature (aerodynamic force quadratic in the air-relative velocity)
+        md0 = models.QuadcopterEuler(0.1).c_struct()
+        g_xx = t(1, N, n, n, n)
+        assert lib.zm_quadratic_dynamics_f64(ctypes.addressof(md0), p(dx), p(du), None, p(g_xx), None, None, 1, N, None) == 0
+        torch.cuda.synchronize()
+        assert float((g_xx - f_xx).abs().max()) > 1e-4

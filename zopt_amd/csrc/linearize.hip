@@ -58,16 +58,23 @@ __global__ __launch_bounds__(64) void linearize_dynamics_kernel(const zm_model_t
     }
 }
 
-// quadratic_dynamics: one wave per (trajectory, step) point; the unordered derivative pairs (a, b) of the variables the model is
-// not affine in are spread over the lanes, each evaluated once on hyper-dual numbers seeded e_a, e_b; every other entry is zero.
+// quadratic_dynamics: the unordered derivative pairs (a, b) that can be nonzero are spread over the lanes, each evaluated once on
+// hyper-dual numbers seeded e_a, e_b; every other entry is zero.  PPW points per wave: 2 when the model declares at most 32 pairs
+// (model_hessian_pairs), else 1 with the pairs of the variables the model is not affine in (model_nonlinear_mask).
+template <int PPW>
 __global__ __launch_bounds__(64) void quadratic_dynamics_kernel(const zm_model_t md, const double* __restrict__ xTraj,
                                                                 const double* __restrict__ uTraj,
                                                                 const int* __restrict__ active, double* __restrict__ f_xx,
                                                                 double* __restrict__ f_ux, double* __restrict__ f_uu,
                                                                 const long batch, const int T, const int* __restrict__ list,
                                                                 const long count) {
-    const long slot = blockIdx.x / T;
-    const int k = (int)(blockIdx.x - slot * T);
+    constexpr int LPP = 64 / PPW;                       // lanes per point
+    const int sub = threadIdx.x / LPP, lp = threadIdx.x % LPP;
+    const long nslot = list ? count : batch;
+    const long sp = (long)blockIdx.x * PPW + sub;       // slot * T + k
+    if (sp >= nslot * T) return;
+    const long slot = sp / T;
+    const int k = (int)(sp - slot * T);
     const long traj = list ? (long)list[slot] : slot;
     if (active && active[traj] == 0) return;
     const long pt = traj * T + k;
@@ -77,35 +84,40 @@ __global__ __launch_bounds__(64) void quadratic_dynamics_kernel(const zm_model_t
     double* oxx = f_xx + pt * n * n * n;
     double* oux = f_ux + pt * n * m * n;
     double* ouu = f_uu + pt * n * m * m;
-    // Only pairs of variables the model is not affine in can have a second derivative (model_nonlinear_mask): everything is
-    // zero-filled with coalesced stores, then the V (V + 1) / 2 pairs of the V nonlinear variables are evaluated -- 45 instead
-    // of 136 hyper-dual evaluations per point for the quadcopter, one round of lanes instead of three.
-    const unsigned mask = model_nonlinear_mask(md);
-    int nl[MAXN + MAXM], V = 0;
-    for (int i = 0; i < K; ++i)
-        if (mask >> i & 1u) nl[V++] = i;
+    // everything is zero-filled with coalesced stores (full lines: leaving the structural zeros unwritten in a buffer zeroed once
+    // is slower, the entries then reach HBM as partial-line writes), then the pairs are evaluated
     {
         const int nxx = n * n * n, nux = n * m * n, nuu = n * m * m;
-        for (int e = threadIdx.x; e < nxx; e += 64) oxx[e] = 0.0;
+        for (int e = lp; e < nxx; e += LPP) oxx[e] = 0.0;
         if (f_ux) {   // NULL (with f_uu): the model is affine in its controls, the caller does not materialise these zeros
-            for (int e = threadIdx.x; e < nux; e += 64) oux[e] = 0.0;
-            for (int e = threadIdx.x; e < nuu; e += 64) ouu[e] = 0.0;
+            for (int e = lp; e < nux; e += LPP) oux[e] = 0.0;
+            for (int e = lp; e < nuu; e += LPP) ouu[e] = 0.0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the zeros land before the entries written below
         __builtin_amdgcn_s_waitcnt(0);
     }
-    const int npairs = V * (V + 1) / 2;
-    for (int p = threadIdx.x; p < npairs; p += 64) {
-        int ia = 0, rem = p;
-        while (rem >= V - ia) {  // row ia of the upper triangle holds V - ia pairs (ia, ia..V-1)
-            rem -= V - ia;
-            ++ia;
-        }
-        int a = 0, b = 0;        // nl[] by a select chain: a dynamic index would put the array into scratch
+    int ta = 0, tb = 0;
+    const int declared = model_hessian_pairs(md, lp, ta, tb);
+    const unsigned mask = model_nonlinear_mask(md);
+    int nl[MAXN + MAXM], V = 0;
+    for (int i = 0; i < K; ++i)
+        if (mask >> i & 1u) nl[V++] = i;
+    const int npairs = declared ? declared : V * (V + 1) / 2;
+    for (int p = lp; p < npairs; p += LPP) {
+        int a = ta, b = tb;
+        if (!declared) {
+            int ia = 0, rem = p;
+            while (rem >= V - ia) {  // row ia of the upper triangle holds V - ia pairs (ia, ia..V-1)
+                rem -= V - ia;
+                ++ia;
+            }
+            a = 0;               // nl[] by a select chain: a dynamic index would put the array into scratch
+            b = 0;
 #pragma unroll
-        for (int q = 0; q < MAXN + MAXM; ++q) {
-            a = (q == ia) ? nl[q] : a;
-            b = (q == ia + rem) ? nl[q] : b;
+            for (int q = 0; q < MAXN + MAXM; ++q) {
+                a = (q == ia) ? nl[q] : a;
+                b = (q == ia + rem) ? nl[q] : b;
+            }
         }
         Hyper x[MAXN], u[MAXM], xn[MAXN];
 #pragma unroll
@@ -314,9 +326,13 @@ extern "C" int zm_quadratic_dynamics_list_f64(const zm_model_t* model, const dou
                                         "controls (zm_model_nonlinear_mask)");
     if (batch < 0 || T < 1) return zm::set_error(ZM_EINVAL, "zm_quadratic_dynamics_f64: bad size");
     if ((rc = zm_check_list("zm_quadratic_dynamics_list_f64", list, count, batch))) return rc;
-    const long nslot = list ? (long)count : (long)batch;
-    hipLaunchKernelGGL(zm::quadratic_dynamics_kernel, dim3((unsigned)(nslot * T)), dim3(64), 0, (hipStream_t)stream, md, xTraj,
-                       uTraj, (const int*)active, f_xx, f_ux, f_uu, (long)batch, T, (const int*)list, (long)count);
+    const long npts = (list ? (long)count : (long)batch) * T;
+    if (md.kind == ZM_MODEL_QUADCOPTER)   // declares 28 pairs (model_hessian_pairs): two points per wave
+        hipLaunchKernelGGL(zm::quadratic_dynamics_kernel<2>, dim3((unsigned)((npts + 1) / 2)), dim3(64), 0, (hipStream_t)stream, md,
+                           xTraj, uTraj, (const int*)active, f_xx, f_ux, f_uu, (long)batch, T, (const int*)list, (long)count);
+    else
+        hipLaunchKernelGGL(zm::quadratic_dynamics_kernel<1>, dim3((unsigned)npts), dim3(64), 0, (hipStream_t)stream, md, xTraj,
+                           uTraj, (const int*)active, f_xx, f_ux, f_uu, (long)batch, T, (const int*)list, (long)count);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }

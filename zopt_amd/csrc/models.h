@@ -167,6 +167,32 @@ __host__ __device__ __forceinline__ unsigned model_nonlinear_mask(const zm_model
     return 0u;
 }
 
+// The unordered variable pairs (a <= b) that can have a nonzero second derivative, for models that declare them: a tighter
+// statement than model_nonlinear_mask (whose V (V + 1) / 2 pairs are the fallback).  Quadcopter, states u v w p q r phi theta psi
+// = 0..8 (quadcopter.py:23-144): the aerodynamic force is quadratic in each body velocity alone; omega x v couples six
+// velocity / rate pairs; gravity, the Euler-angle kinematics and the rotation of the body velocity into the inertial frame couple
+// the angles with each other, with q and r, and with u, v, w (this also covers a constant wind, which enters through the same
+// rotation).  28 pairs instead of 45: two trajectory points share a wave.  tests/test_ddp_gpu.py checks against autograd that
+// every other second derivative is exactly zero.
+constexpr int ZM_MAX_PAIRS = 32;
+__device__ __forceinline__ int model_hessian_pairs(const zm_model_t& md, const int p, int& a, int& b) {
+    if (md.kind == ZM_MODEL_QUADCOPTER) {
+        // packed as a * 16 + b
+        constexpr unsigned char tab[28] = {0x00, 0x11, 0x22,                                       // (u,u) (v,v) (w,w)
+                                           0x24, 0x15, 0x05, 0x23, 0x13, 0x04,                     // omega x v
+                                           0x66, 0x67, 0x77, 0x68, 0x78, 0x88,                     // angle, angle
+                                           0x06, 0x07, 0x08, 0x16, 0x17, 0x18, 0x26, 0x27, 0x28,   // velocity, angle
+                                           0x46, 0x47, 0x56, 0x57};                                // q / r, phi / theta
+        int e = 0;
+#pragma unroll
+        for (int q = 0; q < 28; ++q) e = (q == p) ? tab[q] : e;   // select chain: no dynamic indexing of a local table
+        a = e >> 4;
+        b = e & 15;
+        return 28;
+    }
+    return 0;   // not declared: the caller enumerates the pairs of model_nonlinear_mask
+}
+
 template <typename S>
 __device__ __forceinline__ void model_step(const zm_model_t& md, const S (&x)[MAXN], const S (&u)[MAXM], S (&xn)[MAXN]) {
     if (md.kind == ZM_MODEL_QUADCOPTER) {
