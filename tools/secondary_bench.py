@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Bounded single-GPU measurements of the BASELINE configs that are NOT the headline (configs[2], [3], [4]).
+
+`bench.py` runs these after -- and outside -- its timed region and emits them under "secondary"; the tools/bench_*.py
+command lines call the same functions.  Each returns a plain dict with its own yardstick:
+
+  config2  lqrMpc, 1024 quadcopter instances, N = 30, demo tolerance (demos/lqrMpc.py:11-32): ms per batched solve, ADMM
+           iterations, status mix.  Latency-bound (tiny HBM footprint): no roofline fraction, the number is ms / solve.
+  config3  iterativeLqr and differentialDynamicProgramming, 8192 quadcopter problems, T = 100 (demos/iterativeLqr.py:22-39,
+           demos/differentialDynamicProgramming.py:22-39) -- ONE GPU runs the whole 8192-problem batch here (the config
+           shards it 1024 per GPU over 8): ms per solve, converged fraction.
+  config4  discreteFiniteHorizonLqr at n = 64, m = 16, T = 200, fp32, one GPU's share (2048 of 16384 trajectories):
+           horizon-steps/s and fp32 MFMA TFLOP/s against the 157.3 TFLOP/s dense fp32 matrix peak.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+
+
+def _median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def mpc_problem(N=30):
+    """The demo's MPC design: quadcopter linearised at hover, dt = 0.1, Q = R = I, demo bounds (demos/lqrMpc.py:11-32)."""
+    from zopt_amd import models, mpcUtils, pytrees
+    lin = pytrees.AffineDynamics.from_function(models.QuadcopterEuler(0.1), np.zeros(12), models.QuadcopterEuler.uTrim)
+    A, B = np.asarray(lin.f_x), np.asarray(lin.f_u)            # I + dt*Aw, dt*Bw   (demos/lqrMpc.py:26-28)
+    x_ub = np.array([1, 1, 1, 0.3, 0.3, 0.1, 0.5, 0.5, np.inf, np.inf, np.inf, np.inf])
+    u_ub = np.array([3.0, 3, 3, 3])
+    return mpcUtils.lqrMpc(A, B, np.eye(12), np.eye(4), N, -x_ub, x_ub, -u_ub, u_ub), x_ub
+
+
+def mpc_x0(batch, x_ub, seed=1):
+    rng = np.random.default_rng(seed)
+    x0 = np.clip(0.03 * rng.standard_normal((batch, 12)), -x_ub + 1e-6, x_ub - 1e-6)
+    x0[:, 9:12] = rng.uniform(-10, 10, (batch, 3))
+    return x0
+
+
+def config2_mpc(batch=1024, N=30, eps=1e-2, reps=5, max_iter=100000):
+    import torch
+    prob, x_ub = mpc_problem(N)
+    tx0 = torch.as_tensor(mpc_x0(batch, x_ub), device="cuda")
+    prob.solve(tx0[:64], eps_abs=eps, eps_rel=eps)            # warm-up (Riccati tables, allocator)
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        u0, traj, status = prob.solve(tx0, solver="OSQP", eps_abs=eps, eps_rel=eps, max_iter=max_iter, warm_start=False)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    its = prob.last_iterations
+    t = _median(times)
+    return {"workload": f"BASELINE configs[2]: lqrMpc quadcopter n=12 m=4 N={N}, {batch} instances, eps_abs=eps_rel={eps:g}, cold start",
+            "solve_ms": t * 1e3, "solve_ms_min": min(times) * 1e3, "reps": reps,
+            "optimal_frac": float(np.mean(status == "optimal")),
+            "admm_iters_mean": float(its.mean()), "admm_iters_max": int(its.max()),
+            "instance_solves_per_s": batch / t,
+            "parity": "unpinned (reference arithmetic is OSQP's, absent here; accepted by KKT certificate in tests/test_mpc_gpu.py)"}
+
+
+def config3_problem(batch=8192, T=100, ddp=False, seed=2):
+    from zopt_amd import models
+    rng = np.random.default_rng(seed)
+    x0 = np.zeros((batch, 12))
+    x0[:, 9:12] = rng.uniform(-10, 10, (batch, 3))
+    ug = np.tile(models.QuadcopterEuler.uTrim, (batch, T, 1))
+    cost = models.QuadraticCost(np.eye(12), (0.2 if ddp else 1.0) * np.eye(4), 10 * np.eye(12))
+    return models.QuadcopterEuler(0.1), cost, x0, ug
+
+
+def config3_ilqr(batch=8192, T=100, ddp=False, reps=3):
+    import torch
+    from zopt_amd import ilqrUtils
+    model, cost, x0, ug = config3_problem(batch, T, ddp)
+    solve = ilqrUtils.differentialDynamicProgramming if ddp else ilqrUtils.iterativeLqr
+    tx0, tug = torch.as_tensor(x0, device="cuda"), torch.as_tensor(ug, device="cuda")
+    solve(model, cost, cost, tx0[:64], tug[:64])       # warm-up
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        traj, L, J, conv = solve(model, cost, cost, tx0, tug)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    t = min(times)
+    fin = torch.isfinite(J)
+    name = "differentialDynamicProgramming" if ddp else "iterativeLqr"
+    return {"workload": f"BASELINE configs[3], whole batch on one GPU: {name} quadcopter n=12 m=4 T={T}, {batch} problems, fp64, "
+                        f"R={'0.2' if ddp else '1'}*I, maxIter=100, tol=1e-3",
+            "solve_ms": t * 1e3, "solve_ms_all": [x * 1e3 for x in times], "converged_frac": float(conv.double().mean().item()),
+            "J_mean_finite": float(J[fin].mean().item()), "J_nonfinite_frac": float((~fin).double().mean().item()),
+            "trajectories_per_s": batch / t}
+
+
+def tiled_mfma_per_step(n):
+    nt = (n + 15) // 16
+    return 4 * nt * nt + 4 * nt * (nt + 1) + 4 * nt ** 3 + 4 * nt * nt + 4 * nt + 4 * nt * nt + 4 * nt * nt + 4 * nt ** 3
+
+
+def config4_tiled(batch=2048, T=200, n=64, m=16, reps=3, fp64=False):
+    import torch
+    from zopt_amd import _lib
+    b = batch
+    g = torch.Generator(device="cuda").manual_seed(3)
+    dt = torch.float64 if fp64 else torch.float32
+    rn = lambda *s: torch.randn(*s, device="cuda", dtype=dt, generator=g)   # noqa: E731
+    A1 = rn(b, n, n) * (0.9 / n ** 0.5)
+    B1 = rn(b, n, m)
+    M, N = rn(b, n, n), rn(b, m, m)
+    Q1 = M @ M.transpose(-1, -2) / n + torch.eye(n, device="cuda", dtype=dt)
+    R1 = N @ N.transpose(-1, -2) / m + torch.eye(m, device="cuda", dtype=dt)
+    A, B, Q, R = (X[:, None].expand(b, T, *X.shape[1:]).contiguous() for X in (A1, B1, Q1, R1))
+    del M, N
+    L = torch.empty((b, T, m, n), device="cuda", dtype=dt)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lib = _lib.lib()
+    fn = lib.zm_lqr_backward_f64 if fp64 else lib.zm_lqr_backward_f32
+
+    def call():
+        _lib.check(fn(A.data_ptr(), B.data_ptr(), Q.data_ptr(), R.data_ptr(), L.data_ptr(), b, T, n, m, st), "config4")
+    call()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3)
+    best = min(ts)
+    steps = b * T
+    bytes_step = (8 if fp64 else 4) * (2 * n * n + 2 * n * m + m * m)
+    tflops = steps * tiled_mfma_per_step(n) * 2048 / best / 1e12
+    out = {"workload": f"BASELINE configs[4], one GPU's share: discreteFiniteHorizonLqr n={n} m={m} T={T}, {b} trajectories, "
+                       f"{'fp64' if fp64 else 'fp32'}, inputs generated on the device",
+           "ms": best * 1e3, "ms_all": [x * 1e3 for x in ts], "horizon_steps_per_s": steps / best,
+           "algorithmic_GBps": steps * bytes_step / best / 1e9, "mfma_TFLOPs": tflops,
+           "finite": bool(torch.isfinite(L).all().item())}
+    if not fp64:
+        out["frac_of_fp32_matrix_peak"] = tflops / FP32_MATRIX_PEAK_TFLOPS
+    del A, B, Q, R, L
+    torch.cuda.empty_cache()
+    return out
+
+
+def run_all(budget_s=25.0):
+    """Every secondary measurement, skipping what no longer fits the time budget (the bench line must stay within minutes)."""
+    out, t0 = {}, time.perf_counter()
+    for key, fn in (("configs[2]_lqrMpc", lambda: config2_mpc()),
+                    ("configs[3]_iterativeLqr", lambda: config3_ilqr(ddp=False, reps=3)),
+                    ("configs[3]_differentialDynamicProgramming", lambda: config3_ilqr(ddp=True, reps=2)),
+                    ("configs[4]_lqr_n64_fp32", lambda: config4_tiled())):
+        if time.perf_counter() - t0 > budget_s:
+            out[key] = {"skipped": f"secondary time budget of {budget_s:g} s used up"}
+            continue
+        try:
+            out[key] = fn()
+        except Exception as e:  # noqa: BLE001 -- a failing secondary measurement must not take the headline line with it
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
+    out["seconds"] = time.perf_counter() - t0
+    return out
+
+
+if __name__ == "__main__":
+    import json
+    print(json.dumps(run_all(1e9)))

@@ -30,10 +30,11 @@ def shard_batch(arrays: Sequence, world_size: int = None, rank: int = None):
     return [a[lo:hi] for a in arrays]
 
 
-def allgather_results(local: torch.Tensor, batch: int, group=None) -> torch.Tensor:
+def allgather_results(local: torch.Tensor, batch: int, group=None, out: torch.Tensor = None) -> torch.Tensor:
     """All-gather of per-rank result shards (leading axis = local batch) into the full (batch, ...) tensor on every
     rank.  Equal shards use one `all_gather_into_tensor` (a single RCCL all-gather over xGMI); ragged shards are
-    padded to the largest shard first."""
+    padded to the largest shard first.  `out` (equal shards only): a caller-allocated (batch, ...) receive buffer, so that
+    the one step that can fail on a single rank -- the allocation -- happens before any rank enters the collective."""
     world = dist.get_world_size(group)
     sizes = [shard_bounds(batch, world, r) for r in range(world)]
     counts = [hi - lo for lo, hi in sizes]
@@ -42,9 +43,15 @@ def allgather_results(local: torch.Tensor, batch: int, group=None) -> torch.Tens
         raise ValueError(f"local shard has {local.shape[0]} items, expected {counts[dist.get_rank(group)]}")
     mx = max(counts)
     if min(counts) == mx:
-        out = torch.empty((batch,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        shape = (batch,) + tuple(local.shape[1:])
+        if out is None:
+            out = torch.empty(shape, dtype=local.dtype, device=local.device)
+        elif tuple(out.shape) != shape or out.dtype != local.dtype or not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous {shape} tensor of {local.dtype}")
         dist.all_gather_into_tensor(out, local, group=group)
         return out
+    if out is not None:
+        raise ValueError("out= is only supported for equal shards")
     pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     buf = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
