@@ -527,17 +527,14 @@ def quadratic_dynamics_from_trajectory(f_torch, traj: Trajectory) -> QuadraticDy
     """QuadraticDynamics.from_trajectory (pytrees.py:188-194) by torch autograd on CPU:
     f_xx[i,j,k] = d2f_i/dx_j dx_k, f_ux[i,j,k] = d2f_i/du_j dx_k, f_uu[i,j,k] = d2f_i/du_j du_k."""
     import torch
-    from torch.func import hessian, jacfwd
+    from torch.func import hessian, jacfwd, vmap
     xT, uT = (torch.as_tensor(np.asarray(t), dtype=torch.float64) for t in traj)
-    fs, fx, fu, fxx, fux, fuu = [], [], [], [], [], []
-    for k in range(uT.shape[0]):
-        x, u = xT[k], uT[k]
-        fs.append(f_torch(x, u))
-        jx, ju = jacfwd(f_torch, argnums=(0, 1))(x, u)
-        (hxx, hxu), (hux, huu) = hessian(f_torch, argnums=(0, 1))(x, u)
-        fx.append(jx); fu.append(ju); fxx.append(hxx); fux.append(hux); fuu.append(huu)
-    st = lambda L: torch.stack(L).numpy()
-    return QuadraticDynamics(st(fs), st(fx), st(fu), st(fxx), st(fux), st(fuu))
+    xs = xT[:uT.shape[0]]
+    # vmap over the time steps, as the reference does (pytrees.py:193: jax.vmap(QuadraticDynamics.from_function, ...))
+    fs = vmap(f_torch)(xs, uT)
+    fx, fu = vmap(jacfwd(f_torch, argnums=(0, 1)))(xs, uT)
+    (fxx, _fxu), (fux, fuu) = vmap(hessian(f_torch, argnums=(0, 1)))(xs, uT)
+    return QuadraticDynamics(*(t.numpy() for t in (fs, fx, fu, fxx, fux, fuu)))
 
 
 # ----------------------------------------------------------------------------------------

@@ -118,6 +118,61 @@ def test_ddp_quadcopter_demo_problem(mods):
         assert _rel(traj.xTraj[i], rt.xTraj) <= 1e-6 and _rel(traj.uTraj[i], rt.uTraj) <= 1e-6 and _rel(L[i], rL) <= 1e-5
 
 
+def test_ddp_baseline_config4_full_size(mods):
+    """BASELINE configs[3], DDP leg, at its stated size: 8192 quadcopter problems, T = 100, R = 0.2 I
+    (demos/differentialDynamicProgramming.py:22-39; tools/secondary_bench.config3_ilqr(ddp=True) is the same workload).
+    Size-independent properties on the whole batch, the oracle loop (ilqrUtils.py:360-397 restated) on picked trajectories,
+    and batch-composition independence.  Twin of tests/test_ilqr_solve_gpu.py::test_iterativeLqr_baseline_config4_full_size."""
+    ilqr, models, _, _ = mods
+    batch, N = 8192, 100
+    Q, R, Qf = np.eye(12), 0.2 * np.eye(4), 10 * np.eye(12)
+    cost = models.QuadraticCost(Q, R, Qf)
+    model = models.QuadcopterEuler(0.1)
+    rng = np.random.default_rng(2)
+    x0 = np.zeros((batch, 12))
+    x0[:, 9:12] = rng.uniform(-10, 10, (batch, 3))
+    ug = np.tile(models.QuadcopterEuler.uTrim, (batch, N, 1))
+    traj, L, J, conv = ilqr.differentialDynamicProgramming(model, cost, cost, x0, ug)
+    assert traj.xTraj.shape == (batch, N + 1, 12) and traj.uTraj.shape == (batch, N, 4)
+    assert L.shape == (batch, N, 4, 12) and J.shape == (batch,) and conv.shape == (batch,) and conv.dtype == np.bool_
+    assert conv.mean() > 0.95                                    # nearly every start converges within 100 iterations
+    # the initial guess hovers at x0: J0 = N (x0'Q x0 + uTrim'R uTrim) + x0'Qf x0; the argmin over 16 step sizes (down to
+    # 0.5^15) never accepts a worse trajectory than the previous one, so J is non-increasing from J0 on every finite solve
+    uT = models.QuadcopterEuler.uTrim
+    J0 = (N + 10) * np.sum(x0 ** 2, axis=1) + N * float(uT @ R @ uT)
+    fin = np.isfinite(J)
+    assert fin.mean() > 0.99 and np.all(J[fin] <= J0[fin] * (1 + 1e-12))
+    assert np.all(J[conv] < J0[conv]) and np.all(fin[conv])       # `converged` is never set on a NaN cost (NaN compares false)
+    assert np.all(np.isfinite(traj.xTraj[conv])) and np.all(np.isfinite(L[conv]))
+    assert np.all(traj.xTraj[:, 0] == x0)                         # rollouts start at x0 exactly
+    # dynamics consistency: the returned trajectory is the rollout of its own controls, and J is its cost
+    step = zo.quad_euler_step(0.1)
+    nonconv = np.flatnonzero(~conv & fin)
+    pick = [0, 1234, 4095, 8191] + ([int(nonconv[0])] if nonconv.size else [])
+    for i in pick:
+        x = x0[i].copy()
+        Ji = 0.0
+        for k in range(N):
+            Ji += x @ Q @ x + traj.uTraj[i, k] @ R @ traj.uTraj[i, k]
+            x = step(x, traj.uTraj[i, k])
+            assert np.max(np.abs(x - traj.xTraj[i, k + 1])) <= 1e-9 * max(1.0, np.max(np.abs(x)))
+        Ji += x @ Qf @ x
+        assert J[i] == pytest.approx(Ji, rel=1e-10)
+    # oracle loop on two picked trajectories: same `converged`, same cost, same controls and gains
+    ft = zo.quad_euler_step_torch(0.1)
+    for i in (0, 4095):
+        rt, rL, rJ, rc = zo.differentialDynamicProgramming(step, ft, Q, R, Qf, x0[i], ug[i])
+        assert bool(conv[i]) == rc and J[i] == pytest.approx(rJ, rel=1e-7)
+        if rc:
+            assert _rel(traj.uTraj[i], rt.uTraj) <= 1e-5 and _rel(traj.xTraj[i], rt.xTraj) <= 1e-5 and _rel(L[i], rL) <= 1e-4
+    # batch-composition independence (incl. a start that does not converge, when there is one)
+    sub = np.array(pick)
+    ts, Ls, Js, cs = ilqr.differentialDynamicProgramming(model, cost, cost, x0[sub], ug[sub])
+    assert np.array_equal(cs, conv[sub])
+    assert np.array_equal(Js, J[sub], equal_nan=True)
+    assert np.array_equal(ts.uTraj, traj.uTraj[sub], equal_nan=True) and np.array_equal(Ls, L[sub], equal_nan=True)
+
+
 def test_conditionQuadraticDynamics_matches_oracle():
     """ilqrUtils.py:237-251: contraction with v_x, PD projection of the stacked block, blocks sliced back."""
     from zopt_amd import ilqrUtils, pytrees

@@ -232,7 +232,12 @@ __global__ __launch_bounds__(256) void ilqr_accept_kernel(const int* __restrict_
     const long slot = blockIdx.x;
     if (slot >= count) return;
     const long t = list[slot];
-    if (active[t] == 0) return;   // the list may be older than the mask (it is rebuilt only every few iterations)
+    // The mask is read ONCE per block and shared: thread 0 clears active[t] at the end of this same block, and a wave that
+    // is scheduled late must not see that store and skip its stripe of the copy (a torn trajectory).
+    __shared__ int act;
+    if (threadIdx.x == 0) act = active[t];   // the list may be older than the mask (it is rebuilt only every few iterations)
+    __syncthreads();
+    if (act == 0) return;
     for (long e = threadIdx.x; e < xrow; e += blockDim.x) xT[t * xrow + e] = xT2[t * xrow + e];
     for (long e = threadIdx.x; e < urow; e += blockDim.x) uT[t * urow + e] = uT2[t * urow + e];
     if (threadIdx.x == 0) {

@@ -418,7 +418,7 @@ def _ilqr_or_ddp(dynamics, runningCost, terminalCost, x0, uGuess, maxIter, tol, 
     # host synchronisation (termination test + rebuild of the compacted id list) every SYNC iterations; in between the kernels run
     # on the device-side mask alone -- an iteration over a fully converged batch touches nothing, so the results do not depend on
     # SYNC (measured: 78.5 ms per 8192-problem iLQR solve with 1, 74.7 ms with 4 or 8)
-    SYNC = int(os.environ.get("ZOPT_AMD_ILQR_SYNC", "4"))
+    SYNC = max(1, int(os.environ.get("ZOPT_AMD_ILQR_SYNC", "4")))
     while it < maxIter:                                                                               # (:301-303)
         if it % SYNC == 0:
             if not bool(active.any()):
