@@ -64,5 +64,9 @@ def test_torch_batch_axes_and_iteration_cap(lqr):
     Af, Bf, Qf, Rf = problems.tile_over_horizon(A, B, Q, R, 6)
     Lf = lqr.discreteFiniteHorizonLqr(Af, Bf, Qf, Rf, 6)
     assert np.max(np.abs(Lc - Lf[:, 0])) <= 1e-12 * np.max(np.abs(Lc))      # = L_0 of the 6-step horizon from V = Q
+    with pytest.raises(np.linalg.LinAlgError):          # unconverged at the cap: SciPy raises LinAlgError, never a silent gain
+        lqr.discreteInfiniteHorizonLqr(A, B, Q, R, maxIter=5)
+    with pytest.raises(np.linalg.LinAlgError):          # not stabilizable: unstable mode the input cannot reach
+        lqr.discreteInfiniteHorizonLqr(np.diag([2.0, 0.5]), np.array([[0.0], [1.0]]), np.eye(2), np.eye(1), maxIter=2000)
     with pytest.raises(ValueError):
         lqr.discreteInfiniteHorizonLqr(np.eye(13), np.ones((13, 2)), np.eye(13), np.eye(2))

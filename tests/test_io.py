@@ -52,3 +52,21 @@ def test_interpMapped_matches_componentwise_numpy_interp():
     assert jaxUtils.interpMapped(np.array([0.1, 0.2]), xp, fp).shape == (3, 2)
     f = lambda a: a
     assert jaxUtils.maybeJit(f, True) is f and jaxUtils.maybeJitCls(f) is f
+
+
+def test_plot_adapters_shapes_and_errors():
+    """Arrays for plottingTools.plotTimeTrajectory (plottingTools.py:5-40) and mpcUtils.plotMpcTrajectory (mpcUtils.py:84-122)."""
+    res = dict(xTraj=np.arange(3 * 11 * 12, dtype=np.float64).reshape(3, 11, 12), uTraj=np.zeros((3, 10, 4)))
+    t, x = zio.time_trajectory_inputs(res, 0.1, "xTraj", index=2)
+    assert t.shape == (11,) and x.shape == (11, 12) and np.allclose(t, np.arange(11) * 0.1) and np.array_equal(x, res["xTraj"][2])
+    t, u = zio.time_trajectory_inputs(res, 0.1, "uTraj", index=(0,))
+    assert t.shape == (10,) and u.shape == (10, 4)
+    with pytest.raises(ValueError):
+        zio.time_trajectory_inputs(res, 0.1)                   # batched without an index
+    steps = [np.full((5, 31, 12), float(i)) for i in range(7)]   # 7 closed-loop steps, 5 instances, N_mpc = 31
+    traj = zio.mpc_trajectory_array(steps, index=3)
+    assert traj.shape == (7, 31, 12) and np.array_equal(traj[:, 0, 0], np.arange(7.0))
+    with pytest.raises(ValueError):
+        zio.mpc_trajectory_array(steps)
+    with pytest.raises(ValueError):
+        zio.mpc_trajectory_array([])

@@ -24,7 +24,7 @@ def rel(a, b):
     return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(float(np.max(np.abs(b))), 1e-300))
 
 
-def load(path):
+def _load(path):
     z = np.load(path, allow_pickle=False)
     return {k: (z[k].astype(np.float64) if z[k].dtype == np.float32 else z[k]) for k in z.files}
 
@@ -41,7 +41,7 @@ def test_fixture_files_present_and_labelled():
 
 @pytest.fixture(scope="module", params=FILES, ids=[os.path.basename(f) for f in FILES])
 def fx(request):
-    return load(request.param)
+    return _load(request.param)
 
 
 def test_A1_discreteFiniteHorizonLqr(fx):
@@ -108,9 +108,8 @@ def test_A6_A7_linear_dynamics(fx):
         assert J == pytest.approx(fx["A7_lin_J"][i], rel=1e-12)
 
 
-def test_A10_quadcopter_model_and_rollouts(fx):
-    if "A10_x" not in fx:
-        pytest.skip("quadcopter fixtures exist at (12, 4) only")
+def test_A10_quadcopter_model_and_rollouts():
+    fx = _load(os.path.join(GOLDEN, "ref_n12_m4_T50.npz"))       # the quadcopter (n = 12, m = 4) exists at this shape only
     xs, us = fx["A10_x"], fx["A10_u"]
     for i in range(xs.shape[0]):
         assert rel(zo.quad_inertialDynamics(xs[i], us[i]), fx["A10_xdot"][i]) <= 1e-13

