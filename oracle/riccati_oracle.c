@@ -107,11 +107,16 @@ static void one_trajectory(const double *A, const double *B, const double *Q, co
 int zo_lqr_backward_f64(const double *A, const double *B, const double *Q, const double *R, double *L,
                         int64_t batch, int T, int n, int m, int nthreads) {
     if (n < 1 || m < 1 || n > ZO_MAXN || m > ZO_MAXM || T < 1 || batch < 0) return -1;
+    /* the thread count is a clause of THIS parallel region: the process-wide OpenMP default stays untouched (a one-thread
+       checker call must not turn a later all-cores baseline run into a one-thread run) */
 #ifdef _OPENMP
-    if (nthreads > 0) omp_set_num_threads(nthreads);
+    const int nt = nthreads > 0 ? nthreads : omp_get_max_threads();
+#else
+    const int nt = 1;
 #endif
+    (void)nt;
     const size_t sA = (size_t)T * n * n, sB = (size_t)T * n * m, sR = (size_t)T * m * m, sL = (size_t)T * m * n;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nt)
     for (int64_t b = 0; b < batch; ++b)
         one_trajectory(A + b * sA, B + b * sB, Q + b * sA, R + b * sR, L + b * sL, T, n, m);
     return 0;

@@ -13,7 +13,7 @@ static __device__ __attribute__((aligned(16))) const double zm_zero_src[2] = {0.
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_imm() {
-    static_assert(N >= 0 && N <= 12, "vmcnt immediate");
+    static_assert(N >= 0 && N <= 15, "vmcnt immediate");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -27,20 +27,44 @@ __device__ __forceinline__ void wait_vmcnt_imm() {
     if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
     if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if constexpr (N == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+    if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
 }
 
 // DMA groups retire in issue order and are issued in decreasing step order, so when step j is consumed exactly
-// min(D-1, j) younger groups may still be in flight.  (The L_k stores are NOT counted: that only over-waits.)
-template <int NI, int D>
-__device__ __forceinline__ void wait_for_step(const int j) {
-    if (j >= D - 1) {
-        wait_vmcnt_imm<NI*(D - 1)>();
-    } else if (D >= 3 && j == 1) {
-        wait_vmcnt_imm<NI>();
-    } else if (D >= 4 && j == 2) {
-        wait_vmcnt_imm<2 * NI>();
+// min(D-1, j) younger DMA groups may still be in flight.  vmcnt counts stores too (gfx9: loads, stores and LDS-DMA share the
+// counter, in issue order): a kernel that issues ONE store per step after the DMA of that step has, at the wait for step j,
+// min(D-1, T-1-j) younger stores outstanding on top of the younger DMA groups.  STORES = false ignores them (over-waits: the
+// wait then also drains most of the next step's DMA, i.e. gives away prefetch distance); STORES = true counts them.
+template <int NI, int D, bool STORES = false>
+__device__ __forceinline__ void wait_for_step(const int j, const int T = 0) {
+    if constexpr (STORES) {
+        // issue order (every iteration i: wait(i); operand reads; DMA(i-D); ...; store L(i)), so between DMA(j) -- issued in
+        // iteration j+D, or in the prologue -- and the wait of iteration j lie:  store L(j+D), DMA(j-1), store L(j+D-1), ...,
+        // DMA(j-D+1), store L(j+1).  Younger than DMA(j): min(D-1, j) DMA groups and min(D, T-1-j) stores.
+        const int st = (T - 1 - j) < D ? (T - 1 - j) : D;
+        if (j >= D - 1) {
+            if (st >= D) wait_vmcnt_imm<NI*(D - 1) + D>();          // steady state
+            else if (st == 0) wait_vmcnt_imm<NI*(D - 1)>();          // the first D steps of the sweep: fewer stores behind
+            else if (st == 1) wait_vmcnt_imm<NI*(D - 1) + 1>();
+            else if (st == 2) wait_vmcnt_imm<NI*(D - 1) + 2>();
+            else wait_vmcnt_imm<NI*(D - 1) + 3>();
+        } else {                           // the last D-1 steps: fewer DMA groups behind; stores not counted (over-waits, 2 steps)
+            if (j == 0) wait_vmcnt_imm<0>();
+            else if (j == 1) wait_vmcnt_imm<NI>();
+            else wait_vmcnt_imm<2 * NI>();
+        }
     } else {
-        wait_vmcnt_imm<0>();
+        if (j >= D - 1) {
+            wait_vmcnt_imm<NI*(D - 1)>();
+        } else if (D >= 3 && j == 1) {
+            wait_vmcnt_imm<NI>();
+        } else if (D >= 4 && j == 2) {
+            wait_vmcnt_imm<2 * NI>();
+        } else {
+            wait_vmcnt_imm<0>();
+        }
     }
 }
 

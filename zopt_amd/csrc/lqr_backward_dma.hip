@@ -54,17 +54,35 @@ struct DmaState {
     int oQ, oRm, oBR;      // LDS byte offsets (in a slot) of Q[g][c], R[g][c-n] (or zero pad), [B ; R][c][g]
 };
 
-template <int N, int M, int D>
+// AUX: cache-policy bits of the DMA (sc0 = 1, nt = 2, sc1 = 16).  The product streams its inputs non-temporally (2): every byte
+// is read exactly once, and keeping it out of the L2 / Infinity Cache replacement order is worth 10 % of the kernel's time
+// (tools/k1_lab.hip: 144 -> 128 us per launch; the memory-only variant of the same access pattern 134 -> 119 us).
+template <int N, int M, int D, int AUX = 2>
 __device__ __forceinline__ void dma_issue(DmaState<N, M, D>& a, char* slot) {
     using G = DmaGeom<N, M>;
 #pragma unroll
     for (int i = 0; i < G::NI; ++i) {
-        __builtin_amdgcn_global_load_lds((glb_void_t*)a.p[i], (lds_void_t*)(slot + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)a.p[i], (lds_void_t*)(slot + i * 1024), 16, 0, AUX);
         a.p[i] -= a.st[i];
     }
 }
 
-template <int N, int M, int D, bool G4>
+// X: diagnostic bits for tools/k1_lab.hip (0 in the product): 1 = every block loads the inputs of trajectory blockIdx % 64 (the
+// working set then sits in L2: compute time without HBM latency / bandwidth), 2 = no s_setprio around the solve,
+// 4 = s_memtime stamps per segment, summed into zm_k1_stamps (diagnostic build only: the stamps' waits forbid overlaps).
+#ifdef ZM_K1_LAB
+__device__ unsigned long long zm_k1_stamps[8];
+#define ZM_STAMP(var)                                                                          \
+    if constexpr ((X & 4) != 0) {                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");           \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    }
+#else
+#define ZM_STAMP(var)
+#endif
+
+template <int N, int M, int D, bool G4, int X = 0>
 __global__ __launch_bounds__(64, 4) void lqr_backward_dma_f64(const double* __restrict__ A,
                                                               const double* __restrict__ B,
                                                               const double* __restrict__ Q,
@@ -72,6 +90,7 @@ __global__ __launch_bounds__(64, 4) void lqr_backward_dma_f64(const double* __re
                                                               const int T) {
     using G = DmaGeom<N, M>;
     constexpr int KS = G::KS, NI = G::NI, SLOT = G::SLOT;
+    constexpr int kAux = (X & 16) ? ((X >> 8) & 31) : 2;   // lab: bit 16 selects the policy in bits 8..12; product: nt
     constexpr int nn = N * N, nm = N * M, mm = M * M;
     // ONE LDS object: D ring slots | 4x16 exchange tile of the solve | Y_B = V^T B (n x 4) for the W product.
     constexpr int EXCH = D * SLOT, YBO = EXCH + 64 * 8;
@@ -80,13 +99,14 @@ __global__ __launch_bounds__(64, 4) void lqr_backward_dma_f64(const double* __re
 
     const int lane = threadIdx.x;
     const long traj = blockIdx.x;
+    const long ltraj = (X & 1) ? (long)(blockIdx.x & 63) : traj;   // trajectory whose inputs are loaded (diagnostic bit 1)
     const int g = lane >> 4, c = lane & 15;
     const bool cA = c < N;                    // state column
     const bool cB = (c >= N) && (c < N + M);  // control column
 
     DmaState<N, M, D> a;
     {
-        const long last = traj * T + (T - 1);
+        const long last = ltraj * T + (T - 1);
         const char* At = (const char*)(A + last * nn);
         const char* Bt = (const char*)(B + last * nm);
         const char* Qt = (const char*)(Q + last * nn);
@@ -129,16 +149,19 @@ __global__ __launch_bounds__(64, 4) void lqr_backward_dma_f64(const double* __re
     // prologue: fill the ring with steps T-1 .. T-D
 #pragma unroll
     for (int i = 0; i < D; ++i)
-        if (T - 1 - i >= 0) dma_issue<N, M, D>(a, lds + i * SLOT);
+        if (T - 1 - i >= 0) dma_issue<N, M, D, kAux>(a, lds + i * SLOT);
 
     double V[KS];
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, acc[5] = {0, 0, 0, 0, 0};
+    (void)st0; (void)st1; (void)st2; (void)st3; (void)st4; (void)st5; (void)acc;
     int j = T - 1;  // step index; step j lives in slot (T-1-j) % D
     bool first = true;
     for (;;) {
 #pragma unroll
         for (int si = 0; si < D; ++si) {
             char* slot = lds + si * SLOT;
-            wait_for_step<NI, D>(j);
+            ZM_STAMP(st0)
+            wait_for_step<NI, D, (X & 8) != 0>(j, T);
             d4 f4 = zero4(), q4 = zero4();
 #pragma unroll
             for (int s = 0; s < KS; ++s) f4[s] = *(const double*)(slot + a.oF + s * a.dF);
@@ -147,7 +170,17 @@ __global__ __launch_bounds__(64, 4) void lqr_backward_dma_f64(const double* __re
             const double rm = *(const double*)(slot + a.oRm);
             const double br = *(const double*)(slot + a.oBR);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // operands are in registers: the slot may be refilled
-            if (j - D >= 0) dma_issue<N, M, D>(a, slot);
+            if (j - D >= 0) dma_issue<N, M, D, kAux>(a, slot);
+            ZM_STAMP(st1)
+#ifdef ZM_K1_LAB
+            if constexpr ((X & 32) != 0) {   // memory only: the access pattern's own time (no MFMA, no solve)
+                const double lvm = f4[0] + f4[1] + f4[2] + q4[0] + q4[1] + q4[2] + rm + br;
+                if (vL) { if constexpr ((X & 64) != 0) __builtin_nontemporal_store(lvm, pL); else *pL = lvm; }
+                pL -= nm;
+                if (--j < 0) return;
+                continue;
+            }
+#endif
             if (first) {
 #pragma unroll
                 for (int s = 0; s < KS; ++s) V[s] = q4[s];  // V <- Q[T-1]   (lqrUtils.py:172)
@@ -186,6 +219,7 @@ __global__ __launch_bounds__(64, 4) void lqr_backward_dma_f64(const double* __re
                 srow = gacc[KS] + rm;  // (+ R under the control columns, + 0.0 from the padding elsewhere)
             }
 
+            ZM_STAMP(st2)
             // m x m solve: 4 x 16 tile through LDS, every lane reads Suu (broadcast) and its own RHS column
             exch[g * 16 + c] = srow;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -199,9 +233,10 @@ __global__ __launch_bounds__(64, 4) void lqr_backward_dma_f64(const double* __re
                 b[i] = exch[i * 16 + c];
             }
             const double ybt = *(const double*)(lds + oYBr);
+            ZM_STAMP(st3)
             // The solve is a long chain of short dependent VALU ops; without priority each of them can queue behind a
             // 64-cycle MFMA of another wave on the shared fp64 pipe (measured: -3..4 % kernel time).
-            __builtin_amdgcn_s_setprio(3);
+            if constexpr ((X & 2) == 0) __builtin_amdgcn_s_setprio(3);
             // wave-uniform vote on the scalar unit: "some lane failed the growth check" = ballot(!ok) != 0
             if (__builtin_amdgcn_ballot_w64(!lu_solve4_nopivot(S, b, x)) != 0ull) {
                 // rare: growth check failed somewhere in the wave -> partial pivoting, IEEE division
@@ -212,9 +247,13 @@ __global__ __launch_bounds__(64, 4) void lqr_backward_dma_f64(const double* __re
             const double x23 = (g & 1) ? x[3] : x[2];
             const double lv = (g & 2) ? x23 : x01;  // L_k[g][c]
             const double ln = -lv;
-            __builtin_amdgcn_s_setprio(0);
-            if (vL) *pL = lv;
+            if constexpr ((X & 2) == 0) __builtin_amdgcn_s_setprio(0);
+            if (vL) {
+                if constexpr ((X & 64) != 0) __builtin_nontemporal_store(lv, pL);   // the gains are written once and not re-read here
+                else *pL = lv;
+            }
             pL -= nm;
+            ZM_STAMP(st4)
 
             // [Acl ; -R L] = [A ; 0] + [B ; R] (-L)
             f4 = mfma(br, ln, f4);
@@ -226,6 +265,18 @@ __global__ __launch_bounds__(64, 4) void lqr_backward_dma_f64(const double* __re
             for (int s = 0; s < KS; ++s) q4 = mfma(y[s], f4[s], q4);
 #pragma unroll
             for (int s = 0; s < KS; ++s) V[s] = q4[s];
+#ifdef ZM_K1_LAB
+            if constexpr ((X & 4) != 0) {
+                asm volatile("" ::"v"(V[0]), "v"(V[KS - 1]));
+                ZM_STAMP(st5)
+                acc[0] += st1 - st0; acc[1] += st2 - st1; acc[2] += st3 - st2; acc[3] += st4 - st3; acc[4] += st5 - st4;
+                if (j == 0 && lane == 0) {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) atomicAdd(&zm_k1_stamps[q], acc[q]);
+                    atomicAdd(&zm_k1_stamps[5], 1ull);
+                }
+            }
+#endif
             if (--j < 0) return;
         }
     }
