@@ -487,6 +487,13 @@ __global__ __launch_bounds__(64, 2) void ilqr_backward_t16_f64(
 // K3-DMA: the iLQR sweep (MODE 0) with its per-step operands staged through an LDS ring by DMA, as K1 does
 // (lqr_backward_dma.hip): no operand prefetch registers, no per-step address arithmetic for loads, no vector-memory
 // latency on the chain.  n in {8, 12}, m = 4, 16-B aligned pointers; every other case runs ilqr_backward_t16_f64.
+// Cache policy of the operand DMA (sc0 = 1, nt = 2, sc1 = 16).  Default policy here: unlike K1 (lqr_backward_dma.hip, where
+// non-temporal loads are worth 10 %), the sweeps measured 7 % SLOWER with nt at 8192 x 100 steps (per-step Hessians 616 -> 660 us,
+// affine 722 -> 754 us, shared Hessians unchanged; gpurun_out/r02_ilqr_nt_ab.txt).  -DZM_ILQR_DMA_AUX=2 builds the nt variant.
+#ifndef ZM_ILQR_DMA_AUX
+#define ZM_ILQR_DMA_AUX 0
+#endif
+
 // Slot image of one step (16-B chunks): f_x | f_u | c_x | c_u [| c_xx | c_ux | c_uu unless the Hessians are shared] | zeros.
 namespace zm {
 
@@ -565,7 +572,7 @@ __global__ __launch_bounds__(64, 3) void ilqr_backward_dma_f64(
     auto dma = [&](char* slot) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_void_t*)p[i], (lds_void_t*)(slot + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)p[i], (lds_void_t*)(slot + i * 1024), 16, 0, ZM_ILQR_DMA_AUX);
             p[i] -= st[i];
         }
     };

@@ -82,24 +82,30 @@ __device__ unsigned long long zm_k1_stamps[8];
 #define ZM_STAMP(var)
 #endif
 
-template <int N, int M, int D, bool G4, int X = 0>
-__global__ __launch_bounds__(64, 4) void lqr_backward_dma_f64(const double* __restrict__ A,
-                                                              const double* __restrict__ B,
-                                                              const double* __restrict__ Q,
-                                                              const double* __restrict__ R, double* __restrict__ L,
-                                                              const int T) {
+// W: waves per workgroup.  Wave w of block b owns trajectory b * W + w; the waves never synchronise or share data -- a larger
+// workgroup only makes the co-resident waves of a CU work on ADJACENT trajectories (fewer distinct pages per CU).
+template <int N, int M, int D, bool G4, int X = 0, int W = 1>
+__global__ __launch_bounds__(64 * W, 4) void lqr_backward_dma_f64(const double* __restrict__ A,
+                                                                  const double* __restrict__ B,
+                                                                  const double* __restrict__ Q,
+                                                                  const double* __restrict__ R, double* __restrict__ L,
+                                                                  const int T, const long batch) {
     using G = DmaGeom<N, M>;
     constexpr int KS = G::KS, NI = G::NI, SLOT = G::SLOT;
     constexpr int kAux = (X & 16) ? ((X >> 8) & 31) : 2;   // lab: bit 16 selects the policy in bits 8..12; product: nt
     constexpr int nn = N * N, nm = N * M, mm = M * M;
     // ONE LDS object: D ring slots | 4x16 exchange tile of the solve | Y_B = V^T B (n x 4) for the W product.
     constexpr int EXCH = D * SLOT, YBO = EXCH + 64 * 8;
-    __shared__ __attribute__((aligned(16))) char lds[YBO + N * M * 8];
+    constexpr int PER_WAVE = YBO + N * M * 8;
+    __shared__ __attribute__((aligned(16))) char lds_all[W * PER_WAVE];
+    const int wave = W == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    char* const lds = lds_all + wave * PER_WAVE;
     double* exch = (double*)(lds + EXCH);
 
-    const int lane = threadIdx.x;
-    const long traj = blockIdx.x;
-    const long ltraj = (X & 1) ? (long)(blockIdx.x & 63) : traj;   // trajectory whose inputs are loaded (diagnostic bit 1)
+    const int lane = threadIdx.x & 63;
+    const long traj = (long)blockIdx.x * W + wave;
+    if (traj >= batch) return;   // (whole waves only: no barrier anywhere in this kernel)
+    const long ltraj = (X & 1) ? (traj & 63) : traj;   // trajectory whose inputs are loaded (diagnostic bit 1)
     const int g = lane >> 4, c = lane & 15;
     const bool cA = c < N;                    // state column
     const bool cB = (c >= N) && (c < N + M);  // control column
@@ -175,7 +181,15 @@ __global__ __launch_bounds__(64, 4) void lqr_backward_dma_f64(const double* __re
 #ifdef ZM_K1_LAB
             if constexpr ((X & 32) != 0) {   // memory only: the access pattern's own time (no MFMA, no solve)
                 const double lvm = f4[0] + f4[1] + f4[2] + q4[0] + q4[1] + q4[2] + rm + br;
-                if (vL) { if constexpr ((X & 64) != 0) __builtin_nontemporal_store(lvm, pL); else *pL = lvm; }
+                constexpr int SM = (X >> 13) & 7;   // store shape (diagnostic): 0 = product (48 lanes x 8 B per step)
+                typedef double d2 __attribute__((ext_vector_type(2)));
+                double* const Lk = L + (traj * T + j) * nm;     // L_j: 384 B
+                if constexpr ((X & 128) != 0) { if (lvm == 123.456 && vL) *pL = lvm; }
+                else if constexpr (SM == 1) { if (lane < 24) *(d2*)(Lk + 2 * lane) = d2{lvm, lvm}; }                 // 24 lanes x 16 B per step
+                else if constexpr (SM == 2) { if ((j & 1) == 0 && lane < 48 && j + 1 < T) *(d2*)(Lk + 2 * lane) = d2{lvm, lvm}; }   // 48 x 16 B per 2 steps
+                else if constexpr (SM == 3) { if ((j & 3) == 0 && j + 3 < T) { *(d2*)(Lk + 2 * lane) = d2{lvm, lvm}; if (lane < 32) *(d2*)(Lk + 128 + 2 * lane) = d2{lvm, lvm}; } }
+                else if constexpr (SM == 4) { if ((j & 7) == 0 && j + 7 < T) { *(d2*)(Lk + 2 * lane) = d2{lvm, lvm}; *(d2*)(Lk + 128 + 2 * lane) = d2{lvm, lvm}; *(d2*)(Lk + 256 + 2 * lane) = d2{lvm, lvm}; } }
+                else if (vL) { if constexpr ((X & 64) != 0) __builtin_nontemporal_store(lvm, pL); else *pL = lvm; }
                 pL -= nm;
                 if (--j < 0) return;
                 continue;
@@ -249,7 +263,15 @@ __global__ __launch_bounds__(64, 4) void lqr_backward_dma_f64(const double* __re
             const double ln = -lv;
             if constexpr ((X & 2) == 0) __builtin_amdgcn_s_setprio(0);
             if (vL) {
-                if constexpr ((X & 64) != 0) __builtin_nontemporal_store(lv, pL);   // the gains are written once and not re-read here
+#ifdef ZM_K1_LAB
+                constexpr int SP = (X >> 16) & 7;   // store cache policy (diagnostic): 1 = sc1, 2 = sc0 sc1, 3 = nt sc1, 4 = nt sc0 sc1
+                if constexpr (SP == 1) asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(pL), "v"(lv) : "memory");
+                else if constexpr (SP == 2) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(pL), "v"(lv) : "memory");
+                else if constexpr (SP == 3) asm volatile("global_store_dwordx2 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(pL), "v"(lv) : "memory");
+                else if constexpr (SP == 4) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(pL), "v"(lv) : "memory");
+                else
+#endif
+                if constexpr ((X & 64) != 0) __builtin_nontemporal_store(lv, pL);
                 else *pL = lv;
             }
             pL -= nm;
@@ -297,11 +319,11 @@ static int launch_dma(const double* A, const double* B, const double* Q, const d
     }();
     const dim3 grid((unsigned)batch), block(64);
     if (!g4)
-        hipLaunchKernelGGL((lqr_backward_dma_f64<N, M, 3, false>), grid, block, 0, stream, A, B, Q, R, L, T);
+        hipLaunchKernelGGL((lqr_backward_dma_f64<N, M, 3, false>), grid, block, 0, stream, A, B, Q, R, L, T, (long)batch);
     else if (depth == 2)
-        hipLaunchKernelGGL((lqr_backward_dma_f64<N, M, 2, true>), grid, block, 0, stream, A, B, Q, R, L, T);
+        hipLaunchKernelGGL((lqr_backward_dma_f64<N, M, 2, true>), grid, block, 0, stream, A, B, Q, R, L, T, (long)batch);
     else
-        hipLaunchKernelGGL((lqr_backward_dma_f64<N, M, 3, true>), grid, block, 0, stream, A, B, Q, R, L, T);
+        hipLaunchKernelGGL((lqr_backward_dma_f64<N, M, 3, true>), grid, block, 0, stream, A, B, Q, R, L, T, (long)batch);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }
