@@ -356,6 +356,15 @@ int zm_mpc_solve_adaptive_f64(const double* A, const double* B, const double* K,
                               int warm_start, double* workspace, double* xTraj, double* uTraj, int32_t* status, int32_t* iters,
                               double* resid, int64_t batch, int N, int n, int m, void* stream);
 
+/* Same, with OSQP's over-relaxation `alpha` in (0, 2) (OSQP / cvxpy default 1.6, which is what the reference's
+ * `prob.solve(**kwargs)` runs with, mpcUtils.py:77): the relaxed iterate alpha w + (1 - alpha) y_prev enters the projection and
+ * the dual update; residuals are those of the unrelaxed iterate.  alpha = 1 is zm_mpc_solve_adaptive_f64. */
+int zm_mpc_solve_relaxed_f64(const double* A, const double* B, const double* K, const double* Minv, int n_levels, int level0,
+                             double rho_step, double alpha, const double* x_lb, const double* x_ub, const double* u_lb,
+                             const double* u_ub, const double* x0, double rho, double eps_abs, double eps_rel, double eps_prim_inf,
+                             int max_iter, int warm_start, double* workspace, double* xTraj, double* uTraj, int32_t* status,
+                             int32_t* iters, double* resid, int64_t batch, int N, int n, int m, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

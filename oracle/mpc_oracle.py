@@ -115,8 +115,9 @@ def kkt_residuals(A, B, Q, R, Qf, N, x_lb, x_ub, u_lb, u_ub, x0, x, u, act_tol=1
 
 
 def admm(A, B, Q, R, Qf, N, x_lb, x_ub, u_lb, u_ub, x0, rho=1.0, eps_abs=1e-5, eps_rel=1e-5, max_iter=10000,
-         eps_prim_inf=1e-4):
-    """NumPy restatement of zopt_amd/csrc/mpc.hip for ONE instance.  Returns (x, u, status, iters)."""
+         eps_prim_inf=1e-4, alpha=1.0):
+    """NumPy restatement of zopt_amd/csrc/mpc.hip for ONE instance (fixed penalty).  `alpha` is OSQP's over-relaxation: the
+    relaxed iterate alpha w + (1 - alpha) y_prev enters the projection and the dual update.  Returns (x, u, status, iters)."""
     n, m = B.shape
     if np.any(x0 < x_lb) or np.any(x0 > x_ub):
         return rollout(A, B, x0, np.zeros((N, m))), np.zeros((N, m)), "infeasible", 0
@@ -148,10 +149,11 @@ def admm(A, B, Q, R, Qf, N, x_lb, x_ub, u_lb, u_ub, x0, rho=1.0, eps_abs=1e-5, e
             us.append(-K[k] @ xs[-1] - kf[k])
             xs.append(A @ xs[-1] + B @ us[-1])
         x, u = np.stack(xs), np.stack(us)
-        yxn = np.clip(x[1:] + lx, x_lb, x_ub)
-        yun = np.clip(u + lu, u_lb, u_ub)
-        rx, ru = x[1:] - yxn, u - yun
-        rp = max(np.max(np.abs(rx)), np.max(np.abs(ru)))
+        xh, uh = alpha * x[1:] + (1.0 - alpha) * yx, alpha * u + (1.0 - alpha) * yu     # relaxed iterates (alpha = 1: x, u)
+        yxn = np.clip(xh + lx, x_lb, x_ub)
+        yun = np.clip(uh + lu, u_lb, u_ub)
+        rp = max(np.max(np.abs(x[1:] - yxn)), np.max(np.abs(u - yun)))                 # primal residual of the actual iterate
+        rx, ru = xh - yxn, uh - yun                                                     # dual step
         rd = rho * max(np.max(np.abs(yxn - yx)), np.max(np.abs(yun - yu)))
         lx, lu = lx + rx, lu + ru
         yx, yu = yxn, yun
@@ -171,7 +173,8 @@ def admm(A, B, Q, R, Qf, N, x_lb, x_ub, u_lb, u_ub, x0, rho=1.0, eps_abs=1e-5, e
                 lo_b, hi_b = np.broadcast_to(lo_, r_.shape), np.broadcast_to(hi_, r_.shape)
                 pos, neg = r_ > 0, r_ < 0
                 sup += np.sum(r_[pos] * hi_b[pos]) + np.sum(r_[neg] * lo_b[neg])
-            if gmax <= eps_prim_inf * rp and (s @ x0 - sup) > eps_prim_inf * rp:
+            dn = max(np.max(np.abs(rx)), np.max(np.abs(ru)))
+            if gmax <= eps_prim_inf * dn and (s @ x0 - sup) > eps_prim_inf * dn:
                 status = "infeasible"
                 break
     return x, u, status, it

@@ -104,10 +104,19 @@ def test_quadcopter_config3_batch(mpc):
     for b in range(4):
         kkt = mo.kkt_residuals(A, B, Q, R, Qf, N, -x_ub, x_ub, -u_ub, u_ub, x0[b], trajt.xTraj[b], trajt.uTraj[b], act_tol=5e-3)
         assert kkt["dyn"] <= 1e-11 and kkt["bound"] <= 2e-3 and kkt["stat"] <= 2e-2
-    xo, uo, so, ito = mo.admm(A, B, Q, R, Qf, N, -x_ub, x_ub, -u_ub, u_ub, x0[0], rho=prob.rho, eps_abs=1e-4, eps_rel=1e-4,
-                              max_iter=100000)
-    assert so == "optimal" and ito == int(prob.last_iterations[0])
-    assert np.max(np.abs(trajt.uTraj[0] - uo)) <= 1e-9 and np.max(np.abs(trajt.xTraj[0] - xo)) <= 1e-9
+    # iterate-level agreement: the same number of ADMM iterations and the same iterate, with OSQP's default over-relaxation
+    # (alpha = 1.6, the solve's default) and without (alpha = 1)
+    its_by_alpha = {}
+    for alpha in (1.6, 1.0):
+        _, tra, sta = prob.solve(x0[:1], eps_abs=1e-4, eps_rel=1e-4, max_iter=100000, adaptive_rho=False, alpha=alpha, warm_start=False)
+        xo, uo, so, ito = mo.admm(A, B, Q, R, Qf, N, -x_ub, x_ub, -u_ub, u_ub, x0[0], rho=prob.rho, eps_abs=1e-4, eps_rel=1e-4,
+                                  max_iter=100000, alpha=alpha)
+        assert so == "optimal" and sta[0] == "optimal" and ito == int(prob.last_iterations[0])
+        assert np.max(np.abs(tra.uTraj[0] - uo)) <= 1e-9 and np.max(np.abs(tra.xTraj[0] - xo)) <= 1e-9
+        its_by_alpha[alpha] = ito
+    assert its_by_alpha[1.6] < its_by_alpha[1.0]          # what the relaxation is for
+    with pytest.raises(ValueError):
+        prob.solve(x0[:1], alpha=2.0)
     # the loose (demo tolerance) solutions cost about the same as the tight ones
     for b in range(4):
         ct, cl = mo.cost(Q, R, Qf, trajt.xTraj[b], trajt.uTraj[b]), mo.cost(Q, R, Qf, x[b], u[b])

@@ -51,7 +51,7 @@ def main():
     # receding-horizon run (50 MPC steps, demos/lqrMpc.py:40-47: clip, solve, x <- xTraj[1]), warm-started
     lo = torch.as_tensor(-x_ub + 1e-6, device="cuda")
     hi = torch.as_tensor(x_ub - 1e-6, device="cuda")
-    for warm in (False, "shift"):
+    for warm in ((False, "shift") if args.rh_steps > 0 else ()):
         x = tx0.clone()
         alive = torch.ones(args.batch, dtype=torch.bool, device="cuda")
         iters = 0

@@ -68,6 +68,9 @@ SYMBOLS = {
     "zm_mpc_solve_adaptive_f64": (ctypes.c_int, [_c_dp] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double] + [_c_dp] * 5 +
                                   [ctypes.c_double] * 4 + [ctypes.c_int] * 2 + [_c_dp] * 6 +
                                   [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "zm_mpc_solve_relaxed_f64": (ctypes.c_int, [_c_dp] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double] + [_c_dp] * 5 +
+                                 [ctypes.c_double] * 4 + [ctypes.c_int] * 2 + [_c_dp] * 6 +
+                                 [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "zm_mpc_solve_warm_f64": (ctypes.c_int, [_c_dp] * 9 + [ctypes.c_double] * 4 + [ctypes.c_int] * 2 + [_c_dp] * 6 +
                               [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     # (f_x, f_u, f_xx, f_ux, f_uu, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, active, shared_hessian, l, L, batch, T, n, m, stream)

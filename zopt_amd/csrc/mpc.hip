@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const double* __restrict_
         double x[NS];
 #pragma unroll
         for (int i = 0; i < NS; ++i) x[i] = x0[i];
-        double nrp = 0.0, nrd = 0.0, nw = 0.0, ny = 0.0, nl = 0.0, sup = 0.0;
+        double nrp = 0.0, nrd = 0.0, nw = 0.0, ny = 0.0, nl = 0.0, sup = 0.0, ndl = 0.0;
         auto forward = [&](auto chk_c) {
             constexpr bool CHK = decltype(chk_c)::value;
             double kfc[MC];
@@ -299,15 +299,17 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const double* __restrict_
                     const double hi = (i < NS) ? x_ub[i < NS ? i : 0] : u_ub[i >= NS ? i - NS : 0];
                     const long e = ((long)k * W + i) * bt + ii;
                     const double lold = lb[i], yold = yb[i];
-                    double yn = wv + lold;
+                    const double wh = __builtin_fma(g.alpha, wv, (1.0 - g.alpha) * yold);   // relaxed iterate (alpha = 1: wv exactly)
+                    double yn = wh + lold;
                     yn = yn < lo ? lo : (yn > hi ? hi : yn);
-                    const double r = wv - yn;
-                    const double ln = lold + r;
+                    const double r = wv - yn, dl = wh - yn;   // primal residual; dual step
+                    const double ln = lold + dl;
                     y[e] = done ? yold : yn;       // a finished lane keeps its iterate
                     lam[e] = done ? lold : ln;
                     if constexpr (CHK) {
-                        rv[e] = r;                 // only read back by lanes that are not finished
-                        sup += (r > 0.0) ? r * hi : ((r < 0.0) ? r * lo : 0.0);  // support function of the box at v = r
+                        rv[e] = dl;                // only read back by lanes that are not finished
+                        sup += (dl > 0.0) ? dl * hi : ((dl < 0.0) ? dl * lo : 0.0);  // support function of the box at v = dl
+                        ndl = __builtin_fmax(ndl, __builtin_fabs(dl));
                     }
                     nrp = __builtin_fmax(nrp, __builtin_fabs(r));
                     nrd = __builtin_fmax(nrd, __builtin_fabs(yn - yold));
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const double* __restrict_
             double vw0 = 0.0;  // v^T w(u = 0) = s^T x0   (s = sum_j (A^j)^T vx_j after the sweep)
 #pragma unroll
             for (int i = 0; i < NS; ++i) vw0 = __builtin_fma(sv[i], x0[i], vw0);
-            if (need_cert && gmax <= g.eps_pinf * rp && (vw0 - sup) > g.eps_pinf * rp) {
+            if (need_cert && gmax <= g.eps_pinf * ndl && (vw0 - sup) > g.eps_pinf * ndl) {
                 status = ZM_MPC_INFEASIBLE;
                 done = true;
             }
@@ -475,7 +477,19 @@ extern "C" int zm_mpc_solve_adaptive_f64(const double* A, const double* B, const
                                          double eps_rel, double eps_prim_inf, int max_iter, int warm_start, double* workspace,
                                          double* xTraj, double* uTraj, int32_t* status, int32_t* iters, double* resid,
                                          int64_t batch, int N, int n, int m, void* stream) {
-    if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
+    return zm_mpc_solve_relaxed_f64(A, B, K, Minv, n_levels, level0, rho_step, 1.0, x_lb, x_ub, u_lb, u_ub, x0, rho, eps_abs, eps_rel,
+                                    eps_prim_inf, max_iter, warm_start, workspace, xTraj, uTraj, status, iters, resid, batch, N, n, m,
+                                    stream);
+}
+
+extern "C" int zm_mpc_solve_relaxed_f64(const double* A, const double* B, const double* K, const double* Minv, int n_levels,
+                                        int level0, double rho_step, double alpha, const double* x_lb, const double* x_ub,
+                                        const double* u_lb, const double* u_ub, const double* x0, double rho, double eps_abs,
+                                        double eps_rel, double eps_prim_inf, int max_iter, int warm_start, double* workspace,
+                                        double* xTraj, double* uTraj, int32_t* status, int32_t* iters, double* resid,
+                                        int64_t batch, int N, int n, int m, void* stream) {
+    if (batch == 0) return ZM_OK;
+    if (!(alpha > 0.0 && alpha < 2.0)) return zm::set_error(ZM_EINVAL, "zm_mpc_solve_relaxed_f64: alpha must lie in (0, 2)");   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     if (!A || !B || !K || !Minv || !x_lb || !x_ub || !u_lb || !u_ub || !x0 || !workspace || !xTraj || !uTraj || !status)
         return zm::set_error(ZM_EINVAL, "zm_mpc_solve_f64: null pointer");
     if (batch < 0 || N < 1 || max_iter < 0 || !(rho > 0.0)) return zm::set_error(ZM_EINVAL, "zm_mpc_solve_f64: bad size");
@@ -483,7 +497,7 @@ extern "C" int zm_mpc_solve_adaptive_f64(const double* A, const double* B, const
         return zm::set_error(ZM_EINVAL, "zm_mpc_solve_adaptive_f64: bad penalty levels");
     zm::MpcTabs t{A, B, K, Minv, x_lb, x_ub, u_lb, u_ub};
     zm::MpcArgs g{x0, rho, eps_abs, eps_rel, eps_prim_inf, max_iter, warm_start == 2 ? 2 : (warm_start ? 1 : 0), workspace, xTraj, uTraj, (int*)status, (int*)iters, resid,
-                  (long)batch, N, n_levels, level0, rho_step};
+                  (long)batch, N, n_levels, level0, rho_step, alpha};
     hipStream_t st = (hipStream_t)stream;
     // default: 16 lanes per instance with the iterates in LDS (mpc_wave.hip); ZOPT_AMD_MPC_PATH=lane forces the
     // lane-per-instance kernel below, which also takes the horizons that do not fit LDS (fixed penalty: level0 only)

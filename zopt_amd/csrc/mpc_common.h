@@ -17,6 +17,8 @@ struct MpcArgs {
     // adaptive penalty (OSQP's adaptive_rho): tables for n_levels penalties rho * rho_step^(l - level0), level-major in K / Minv
     int n_levels, level0;
     double rho_step;
+    // over-relaxation (OSQP's alpha; 1 = plain ADMM): w_hat = alpha w + (1 - alpha) y_prev enters the projection and the dual update
+    double alpha;
 };
 
 struct MpcTabs {

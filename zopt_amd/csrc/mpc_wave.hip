@@ -16,29 +16,61 @@
 
 namespace zm {
 
+// acc += c * (value of lane L of this lane's 16-lane row of v): ONE instruction.  gfx90a+ accept a DPP source operand on
+// 64-bit ALU instructions for exactly one control, row_newbcast -- the one a mat-vec needs -- so the broadcast costs no
+// instruction of its own (two v_mov_b32_dpp + the FMA before: a third of the kernel's vector instructions were broadcasts).
+// hipcc pads nothing inside asm: the two wait states a DPP read needs after a VALU write of its source come from dpp_src(),
+// which every mat-vec passes its vector through once (the broadcasts then depend on that statement, hence follow it).
 template <int L>
-__device__ __forceinline__ double bc16(const double v) {   // value of lane L of this lane's 16-lane row
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + L, 0xf, 0xf, false);   // row_newbcast:L
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + L, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
+__device__ __forceinline__ void fma_bc(double& acc, const double c, const double v) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(c), "i"(L));
 }
-// a1 += sum_l c1[l] v_l,  a2 += sum_l c2[l] v_l   over the first NL lanes of the row (one broadcast feeds both)
-template <int NL, int L = 0>
+__device__ __forceinline__ double dpp_src(double v) {
+    asm("s_nop 1" : "+v"(v));
+    return v;
+}
+// a1 += sum_l c1[l] v_l,  a2 += sum_l c2[l] v_l   over the first NL lanes of the row.  The sums run as PS interleaved partial
+// chains (term l goes to chain l % PS): a single chain of 12 dependent FMAs is the longest dependency of a stage, and the
+// solve is the latency of 60 such stages per ADMM iteration.
+template <int NL, int PS, int L = 0>
+__device__ __forceinline__ void mv2_acc(const double (&c1)[NL], const double (&c2)[NL], const double v, double (&s1)[PS],
+                                        double (&s2)[PS]) {
+    if constexpr (L < NL) {
+        fma_bc<L>(s1[L % PS], c1[L], v);
+        fma_bc<L>(s2[L % PS], c2[L], v);
+        mv2_acc<NL, PS, L + 1>(c1, c2, v, s1, s2);
+    }
+}
+template <int NL>
 __device__ __forceinline__ void mv2(const double (&c1)[NL], const double (&c2)[NL], const double v, double& a1, double& a2) {
-    if constexpr (L < NL) {
-        const double b = bc16<L>(v);
-        a1 = __builtin_fma(c1[L], b, a1);
-        a2 = __builtin_fma(c2[L], b, a2);
-        mv2<NL, L + 1>(c1, c2, v, a1, a2);
+    constexpr int PS = NL >= 9 ? 3 : (NL >= 4 ? 2 : 1);
+    double s1[PS], s2[PS];
+    s1[0] = a1;
+    s2[0] = a2;
+#pragma unroll
+    for (int i = 1; i < PS; ++i) s1[i] = s2[i] = 0.0;
+    mv2_acc<NL, PS>(c1, c2, dpp_src(v), s1, s2);
+    if constexpr (PS == 3) {
+        a1 = (s1[0] + s1[1]) + s1[2];
+        a2 = (s2[0] + s2[1]) + s2[2];
+    } else if constexpr (PS == 2) {
+        a1 = s1[0] + s1[1];
+        a2 = s2[0] + s2[1];
+    } else {
+        a1 = s1[0];
+        a2 = s2[0];
     }
 }
 template <int NL, int L = 0>
-__device__ __forceinline__ void mv1(const double (&c1)[NL], const double v, double& a1) {
+__device__ __forceinline__ void mv1_acc(const double (&c1)[NL], const double v, double& a1) {
     if constexpr (L < NL) {
-        a1 = __builtin_fma(c1[L], bc16<L>(v), a1);
-        mv1<NL, L + 1>(c1, v, a1);
+        fma_bc<L>(a1, c1[L], v);
+        mv1_acc<NL, L + 1>(c1, v, a1);
     }
+}
+template <int NL>
+__device__ __forceinline__ void mv1(const double (&c1)[NL], const double v, double& a1) {
+    mv1_acc<NL>(c1, dpp_src(v), a1);
 }
 __device__ __forceinline__ double row_max(double v) {
 #pragma unroll
@@ -127,23 +159,34 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
         }
     }
 
-    // table rows / columns of one stage: K row (control lanes), K column (state lanes), Suu^-1 row (control lanes)
-    auto load_tab = [&](const int k, double (&Krow)[NS], double (&Kcol)[MC], double (&Mrow)[MC]) {
+    // Table rows / columns of one stage: K row (control lanes), K column (state lanes), Suu^-1 row (control lanes).  No masking:
+    // a lane outside the role loads the finite entries of row / column 0 and computes a finite value nobody reads (only lanes
+    // < MC of qu / kf / u and lanes < NS of p / x are ever broadcast or stored).  Stage indices are clamped into [0, N).
+    // ... and with them the lane's own iterates of that stage from LDS (y, lam, kf: stage-local, so reading them stages ahead of
+    // their use is safe in both sweeps): no LDS round trip at the head of a stage's dependency chain.
+    struct Tab {
+        double Krow[NS], Kcol[MC], Mrow[MC];
+        double yx, lx, yu, lu, kf;
+    };
+    auto load_tab = [&](int k, Tab& t) {
+        k = k < 0 ? 0 : (k >= N ? N - 1 : k);
+        t.yx = yx[k * WS_STAGE];
+        t.lx = lx[k * WS_STAGE];
+        t.yu = yu[k * WS_STAGE];
+        t.lu = lu[k * WS_STAGE];
+        t.kf = kf[k * WS_STAGE];
         const double* Kk = Ktab + ((long)lvl * N + k) * MC * NS;
         const double* Mk = Mtab + ((long)lvl * N + k) * MC * MC;
 #pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            const double v = Kk[iu * NS + i];
-            Krow[i] = su ? v : 0.0;
-        }
+        for (int i = 0; i < NS; ++i) t.Krow[i] = Kk[iu * NS + i];
 #pragma unroll
         for (int j = 0; j < MC; ++j) {
-            const double v = Kk[j * NS + ix], w = Mk[iu * MC + j];
-            Kcol[j] = sx ? v : 0.0;
-            Mrow[j] = su ? w : 0.0;
+            t.Kcol[j] = Kk[j * NS + ix];
+            t.Mrow[j] = Mk[iu * MC + j];
         }
     };
 
+    const double alpha = g.alpha, om_alpha = 1.0 - g.alpha;
     int status = x0_in ? 0 : ZM_MPC_INFEASIBLE;
     int it = 0;
     double rp = 0.0, rd = 0.0;
@@ -151,58 +194,62 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
     for (int gi = 0; gi < g.max_iter; ++gi) {
         if (__all(done)) break;
         const bool chk = ((gi + 1) % 25) == 0;
-        // ---- backward affine sweep
+        // ---- backward affine sweep.  The table slices come from L2 (~500+ cycles) and a stage is shorter than that, so they are
+        //      fetched THREE stages ahead into a rotating set of registers (the loop is unrolled by three: no copies).
         double pp = 0.0;   // (A^T p - K^T Qu) of the stage above
         {
-            double Krow[NS], Kcol[MC], Mrow[MC];
-            load_tab(N - 1, Krow, Kcol, Mrow);
-#pragma unroll 1
-            for (int k = N - 1; k >= 0; --k) {
-                double Krn[NS], Kcn[MC], Mrn[MC];
-                load_tab(k > 0 ? k - 1 : 0, Krn, Kcn, Mrn);   // one stage ahead
-                const double zx = -rho * (yx[k * WS_STAGE] - lx[k * WS_STAGE]);
-                const double zu = su ? -rho * (yu[k * WS_STAGE] - lu[k * WS_STAGE]) : 0.0;
-                const double kfo = kf[k * WS_STAGE];
+            auto bstage = [&](const int k, const Tab& t) {
+                const double zx = -rho * (t.yx - t.lx);
+                const double zu = su ? -rho * (t.yu - t.lu) : 0.0;
+                const double kfo = t.kf;
                 const double p = pp + zx;             // costate of x_{k+1}
                 double qu = zu, pa = 0.0;
                 mv2<NS>(Bcol, Acol, p, qu, pa);       // Qu = -rho z_u + B^T p (control lanes);  A^T p (state lanes)
                 double kfv = 0.0, pk = 0.0;
-                mv2<MC>(Mrow, Kcol, qu, kfv, pk);     // kf = Suu^-1 Qu;  K^T Qu
+                mv2<MC>(t.Mrow, t.Kcol, qu, kfv, pk); // kf = Suu^-1 Qu;  K^T Qu
                 if (su) kf[k * WS_STAGE] = done ? kfo : kfv;
                 pp = pa - pk;
-#pragma unroll
-                for (int i = 0; i < NS; ++i) Krow[i] = Krn[i];
-#pragma unroll
-                for (int j = 0; j < MC; ++j) {
-                    Kcol[j] = Kcn[j];
-                    Mrow[j] = Mrn[j];
-                }
+            };
+            Tab t0, t1, t2;
+            load_tab(N - 1, t0);
+            load_tab(N - 2, t1);
+            load_tab(N - 3, t2);
+            int k = N - 1;
+#pragma unroll 1
+            for (; k >= 2; k -= 3) {
+                bstage(k, t0);
+                load_tab(k - 3, t0);
+                bstage(k - 1, t1);
+                load_tab(k - 4, t1);
+                bstage(k - 2, t2);
+                load_tab(k - 5, t2);
             }
+            if (k >= 0) bstage(k, t0);
+            if (k >= 1) bstage(k - 1, t1);
         }
         // ---- forward rollout, projection, dual update, residuals
         double x = x0;
-        double nrp = 0.0, nrd = 0.0, nw = 0.0, ny = 0.0, nl = 0.0, sup = 0.0;
+        double nrp = 0.0, nrd = 0.0, nw = 0.0, ny = 0.0, nl = 0.0, sup = 0.0, ndl = 0.0;
         {
-            double Krow[NS], Kcol[MC], Mrow[MC];
-            load_tab(0, Krow, Kcol, Mrow);
-#pragma unroll 1
-            for (int k = 0; k < N; ++k) {
-                double Krn[NS], Kcn[MC], Mrn[MC];
-                load_tab(k + 1 < N ? k + 1 : N - 1, Krn, Kcn, Mrn);
+            auto fstage = [&](const int k, const Tab& t) {
                 double ku = 0.0, xn = 0.0;
-                mv2<NS>(Krow, Arow, x, ku, xn);       // K x (control lanes), A x (state lanes)
-                const double u = su ? -kf[k * WS_STAGE] - ku : 0.0;
+                mv2<NS>(t.Krow, Arow, x, ku, xn);     // K x (control lanes), A x (state lanes)
+                const double u = su ? -t.kf - ku : 0.0;
                 mv1<MC>(Brow, u, xn);                 // + B u
                 {   // state component
-                    const double lold = lx[k * WS_STAGE], yold = yx[k * WS_STAGE];
-                    double yn = xn + lold;
+                    const double lold = t.lx, yold = t.yx;
+                    const double xh = __builtin_fma(alpha, xn, om_alpha * yold);   // relaxed iterate (alpha = 1: xn exactly)
+                    double yn = xh + lold;
                     yn = yn < xlo ? xlo : (yn > xhi ? xhi : yn);
-                    const double r = xn - yn, ln = lold + r;
+                    const double r = xn - yn, dl = xh - yn, ln = lold + dl;        // primal residual; dual step
                     yx[k * WS_STAGE] = (done || !sx) ? yold : yn;
                     lx[k * WS_STAGE] = (done || !sx) ? lold : ln;
-                    if (chk) rx[k * WS_STAGE] = sx ? r : 0.0;
+                    if (chk) rx[k * WS_STAGE] = sx ? dl : 0.0;
                     if (sx) {
-                        if (chk) sup += (r > 0.0) ? r * xhi : ((r < 0.0) ? r * xlo : 0.0);
+                        if (chk) {
+                            sup += (dl > 0.0) ? dl * xhi : ((dl < 0.0) ? dl * xlo : 0.0);
+                            ndl = __builtin_fmax(ndl, __builtin_fabs(dl));
+                        }
                         nrp = __builtin_fmax(nrp, __builtin_fabs(r));
                         nrd = __builtin_fmax(nrd, __builtin_fabs(yn - yold));
                         nw = __builtin_fmax(nw, __builtin_fabs(xn));
@@ -211,15 +258,17 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
                     }
                 }
                 if (su) {   // control component
-                    const double lold = lu[k * WS_STAGE], yold = yu[k * WS_STAGE];
-                    double yn = u + lold;
+                    const double lold = t.lu, yold = t.yu;
+                    const double uh = __builtin_fma(alpha, u, om_alpha * yold);
+                    double yn = uh + lold;
                     yn = yn < ulo ? ulo : (yn > uhi ? uhi : yn);
-                    const double r = u - yn, ln = lold + r;
+                    const double r = u - yn, dl = uh - yn, ln = lold + dl;
                     yu[k * WS_STAGE] = done ? yold : yn;
                     lu[k * WS_STAGE] = done ? lold : ln;
                     if (chk) {
-                        ru[k * WS_STAGE] = r;
-                        sup += (r > 0.0) ? r * uhi : ((r < 0.0) ? r * ulo : 0.0);
+                        ru[k * WS_STAGE] = dl;
+                        sup += (dl > 0.0) ? dl * uhi : ((dl < 0.0) ? dl * ulo : 0.0);
+                        ndl = __builtin_fmax(ndl, __builtin_fabs(dl));
                     }
                     nrp = __builtin_fmax(nrp, __builtin_fabs(r));
                     nrd = __builtin_fmax(nrd, __builtin_fabs(yn - yold));
@@ -228,14 +277,23 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
                     nl = __builtin_fmax(nl, __builtin_fabs(ln));
                 }
                 x = sx ? xn : 0.0;
-#pragma unroll
-                for (int i = 0; i < NS; ++i) Krow[i] = Krn[i];
-#pragma unroll
-                for (int j = 0; j < MC; ++j) {
-                    Kcol[j] = Kcn[j];
-                    Mrow[j] = Mrn[j];
-                }
+            };
+            Tab t0, t1, t2;
+            load_tab(0, t0);
+            load_tab(1, t1);
+            load_tab(2, t2);
+            int k = 0;
+#pragma unroll 1
+            for (; k + 2 < N; k += 3) {
+                fstage(k, t0);
+                load_tab(k + 3, t0);
+                fstage(k + 1, t1);
+                load_tab(k + 4, t1);
+                fstage(k + 2, t2);
+                load_tab(k + 5, t2);
             }
+            if (k < N) fstage(k, t0);
+            if (k + 1 < N) fstage(k + 1, t1);
         }
         nrp = row_max(nrp);
         nrd = row_max(nrd);
@@ -296,7 +354,8 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
             }
             gmax = row_max(gmax);
             const double vw0 = row_sum(sv * x0);
-            if (need_cert && gmax <= g.eps_pinf * rp && (vw0 - sup) > g.eps_pinf * rp) {
+            const double dn = row_max(ndl);          // |dual step|: the certificate's scale (= rp without relaxation)
+            if (need_cert && gmax <= g.eps_pinf * dn && (vw0 - sup) > g.eps_pinf * dn) {
                 status = ZM_MPC_INFEASIBLE;
                 done = true;
             }
@@ -306,12 +365,12 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
     if (live) {
         double x = x0;
         if (sx) g.xTraj[(inst * (N + 1)) * NS + ix] = x;
-        double Krow[NS], Kcol[MC], Mrow[MC];
+        Tab tf;
 #pragma unroll 1
         for (int k = 0; k < N; ++k) {
-            load_tab(k, Krow, Kcol, Mrow);
+            load_tab(k, tf);
             double ku = 0.0, xn = 0.0;
-            mv2<NS>(Krow, Arow, x, ku, xn);
+            mv2<NS>(tf.Krow, Arow, x, ku, xn);
             const double u = su ? -kf[k * WS_STAGE] - ku : 0.0;
             mv1<MC>(Brow, u, xn);
             if (su) g.uTraj[(inst * N + k) * MC + iu] = u;

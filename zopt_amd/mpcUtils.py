@@ -113,6 +113,7 @@ class lqrMpc():
             **kwargs : solver options, named as the OSQP options the reference forwards through cvxpy
                 (demos/lqrMpc.py:32): eps_abs, eps_rel (default 1e-5, cvxpy's OSQP default), max_iter (default 10000),
                 rho, adaptive_rho (default True: the penalty moves between 7 tabulated levels rho * 5^l as OSQP's does),
+                alpha (over-relaxation in (0, 2); default 1.6, OSQP's default, i.e. what the reference's solve runs with),
                 eps_prim_inf (default 1e-4), warm_start (default True, as cvxpy: a solve for the same batch shape
                 starts from the previous solve's ADMM iterates; `warm_start="shift"` (extension) advances them by one
                 horizon step first, the right guess inside the receding-horizon loop of demos/lqrMpc.py:41-48);
@@ -134,6 +135,9 @@ class lqrMpc():
         rho = float(kwargs.pop("rho", self.rho))
         adaptive = bool(kwargs.pop("adaptive_rho", True))        # OSQP / cvxpy default
         eps_pinf = float(kwargs.pop("eps_prim_inf", 1e-4))
+        alpha = float(kwargs.pop("alpha", 1.6))
+        if not (0.0 < alpha < 2.0):
+            raise ValueError("alpha must lie in (0, 2)")
         warm = kwargs.pop("warm_start", kwargs.pop("warm_starting", True))
         shift = isinstance(warm, str) and warm == "shift"     # extension: previous iterates advanced by one horizon step
         warm = bool(warm)
@@ -163,8 +167,8 @@ class lqrMpc():
         st = torch.empty(Bn, dtype=torch.int32, device=dev)
         its = torch.empty(Bn, dtype=torch.int32, device=dev)
         res = torch.empty((Bn, 2), dtype=torch.float64, device=dev)
-        rc = _lib.lib().zm_mpc_solve_adaptive_f64(d["A"].data_ptr(), d["B"].data_ptr(), K.data_ptr(), Mi.data_ptr(), n_levels,
-                                                  level0, self.RHO_STEP, d["x_lb"].data_ptr(), d["x_ub"].data_ptr(),
+        rc = _lib.lib().zm_mpc_solve_relaxed_f64(d["A"].data_ptr(), d["B"].data_ptr(), K.data_ptr(), Mi.data_ptr(), n_levels,
+                                                  level0, self.RHO_STEP, alpha, d["x_lb"].data_ptr(), d["x_ub"].data_ptr(),
                                                   d["u_lb"].data_ptr(), d["u_ub"].data_ptr(), dx0.data_ptr(), rho, eps_abs,
                                                   eps_rel, eps_pinf, max_iter, (2 if shift else 1) if warm else 0,
                                                   ws.data_ptr(), xT.data_ptr(), uT.data_ptr(), st.data_ptr(), its.data_ptr(),
