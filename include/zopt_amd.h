@@ -356,6 +356,42 @@ int zm_mpc_solve_adaptive_f64(const double* A, const double* B, const double* K,
                               int warm_start, double* workspace, double* xTraj, double* uTraj, int32_t* status, int32_t* iters,
                               double* resid, int64_t batch, int N, int n, int m, void* stream);
 
+/* Second derivatives in PACKED form, for models that declare which variable pairs can have a nonzero second derivative.
+ * zm_model_hessian_pairs: pairs (2 * npairs int32, host, may be NULL) <- (a, b), a <= b, in the stacked variable index (states
+ *     0..n-1, controls n..n+m-1); npairs (host) <- their number, 0 if the model declares none.  The quadcopter declares 28.
+ * zm_quadratic_dynamics_pairs_list_f64: H (batch,T,npairs,n) <- d2 f_i / dz_a dz_b: the nonzero entries of
+ *     QuadraticDynamics.from_trajectory's f_xx / f_ux / f_uu (zopt/pytrees.py:180-194), 2 688 B per point for the quadcopter
+ *     instead of 19 968 B of mostly zeros; `list` / `active` as in zm_quadratic_dynamics_list_f64 (list may be NULL).
+ * zm_ddp_backward_pairs_list_f64: zm_ddp_backward_list_f64 (zopt/ilqrUtils.py:184-214, 237-251) reading H instead of the three
+ *     tensors -- the contraction sum_i v_x[i] H[p][i] runs in the same order, so the policy is bitwise the same.  Used by
+ *     zm_ilqr_solve_f64; the array-level API (full tensors) is zm_ddp_backward_f64. */
+int zm_model_hessian_pairs(const zm_model_t* model, int32_t* pairs, int32_t* npairs);
+int zm_quadratic_dynamics_pairs_list_f64(const zm_model_t* model, const double* xTraj, const double* uTraj, const int32_t* list,
+                                         int64_t count, const int32_t* active, double* H, int64_t batch, int T, void* stream);
+int zm_ddp_backward_pairs_list_f64(const zm_model_t* model, const double* f_x, const double* f_u, const double* H,
+                                   const double* c_x, const double* c_u, const double* c_xx, const double* c_ux,
+                                   const double* c_uu, const double* vf_x, const double* vf_xx, const int32_t* list, int64_t count,
+                                   const int32_t* active, int shared_hessian, double* l, double* L, int64_t batch, int T,
+                                   void* stream);
+
+/* The whole iLQR / DDP solve of a batch as one call: the outer loop of zopt/ilqrUtils.py:290-327 (iterativeLqr, ddp = 0) and
+ * :360-397 (differentialDynamicProgramming, ddp != 0) for a registered model and quadratic cost -- initial rollout of
+ * (uGuess, L = 0), then per iteration the expansions along the trajectory, the PD-conditioned Hessians, the backward pass, the
+ * 16-way line search and `converged = |J - J_new| <= tol`, each over the compacted list of the trajectories that have not
+ * converged yet (rebuilt on the device every `sync_every` >= 1 iterations; results do not depend on it).  The host side of the
+ * loop runs inside this call; it synchronises the stream every `sync_every` iterations and returns with work possibly still
+ * queued on `stream`.
+ * in : x0 (batch,n)  uGuess (batch,T,m)  [device]
+ *      workspace: at least zm_ilqr_solve_workspace_f64(model, batch, T, ddp) doubles, 16-B aligned [device]
+ *      iwork: 2 * batch + 2 int32 [device]
+ * out: xTraj (batch,T+1,n)  uTraj (batch,T,m)  L (batch,T,m,n)  J (batch)  converged (batch) int32  [device]
+ *      iterations: HOST int32 or NULL -- iterations the loop ran (<= max_iter) */
+int64_t zm_ilqr_solve_workspace_f64(const zm_model_t* model, int64_t batch, int T, int ddp);
+int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0, const double* uGuess, int ddp,
+                      int max_iter, double tol, int sync_every, double* workspace, int64_t workspace_doubles, int32_t* iwork,
+                      double* xTraj, double* uTraj, double* L, double* J, int32_t* converged, int32_t* iterations, int64_t batch,
+                      int T, void* stream);
+
 /* Same, with OSQP's over-relaxation `alpha` in (0, 2) (OSQP / cvxpy default 1.6, which is what the reference's
  * `prob.solve(**kwargs)` runs with, mpcUtils.py:77): the relaxed iterate alpha w + (1 - alpha) y_prev enters the projection and
  * the dual update; residuals are those of the unrelaxed iterate.  alpha = 1 is zm_mpc_solve_adaptive_f64. */

@@ -301,3 +301,53 @@ def test_declared_hessian_pairs_cover_every_second_derivative(mods, wind):
         assert lib.zm_quadratic_dynamics_f64(ctypes.addressof(md0), p(dx), p(du), None, p(g_xx), None, None, 1, N, None) == 0
         torch.cuda.synchronize()
         assert float((g_xx - f_xx).abs().max()) > 1e-4
+
+
+def test_packed_second_derivatives_match_the_full_tensors(mods):
+    """zm_model_hessian_pairs / zm_quadratic_dynamics_pairs_list_f64 / zm_ddp_backward_pairs_list_f64 (the form the fused DDP
+    driver uses): the packed entries are exactly the nonzero entries of f_xx (QuadraticDynamics.from_trajectory, pytrees.py:180-194),
+    every other entry of f_xx is exactly zero, and the sweep over the packed form returns bit for bit the policy of
+    zm_ddp_backward_f64 over the full tensors (ilqrUtils.py:184-214, 237-251)."""
+    import ctypes
+    import torch
+    ilqr, models, pt, _lib = mods
+    lib = _lib.lib()
+    rng = np.random.default_rng(41)
+    b, T, n, m = 5, 9, 12, 4
+    model = models.QuadcopterEuler(0.1, wind_ned=(1.0, -2.0, 0.5))
+    md = model.c_struct()
+    pmd = ctypes.addressof(md)
+    npairs = ctypes.c_int32(0)
+    pairs = (ctypes.c_int32 * 64)()
+    _lib.check(lib.zm_model_hessian_pairs(pmd, ctypes.addressof(pairs), ctypes.addressof(npairs)), "pairs")
+    P = npairs.value
+    ab = np.array(pairs[:2 * P]).reshape(P, 2)
+    assert P == 28 and np.all(ab[:, 0] <= ab[:, 1]) and np.all(ab < 9) and len({tuple(x) for x in ab}) == P
+    xT = torch.as_tensor(0.4 * rng.standard_normal((b, T + 1, n)), device="cuda")
+    uT = torch.as_tensor(models.QuadcopterEuler.uTrim + rng.standard_normal((b, T, m)), device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    H = torch.full((b, T, P, n), float("nan"), dtype=torch.float64, device="cuda")
+    _lib.check(lib.zm_quadratic_dynamics_pairs_list_f64(pmd, xT.data_ptr(), uT.data_ptr(), None, 0, None, H.data_ptr(), b, T, st), "packed")
+    f_xx = torch.empty((b, T, n, n, n), dtype=torch.float64, device="cuda")
+    _lib.check(lib.zm_quadratic_dynamics_f64(pmd, xT.data_ptr(), uT.data_ptr(), None, f_xx.data_ptr(), None, None, b, T, st), "full")
+    Hn, F = H.cpu().numpy(), f_xx.cpu().numpy()
+    assert np.all(np.isfinite(Hn))
+    rebuilt = np.zeros_like(F)
+    for p, (a, bb) in enumerate(ab):
+        rebuilt[:, :, :, a, bb] = Hn[:, :, p, :]
+        rebuilt[:, :, :, bb, a] = Hn[:, :, p, :]
+    assert np.array_equal(rebuilt, F)                                   # same entries, and everything else exactly zero
+    # the sweep: packed operand vs full tensors (f_ux = f_uu = NULL: the quadcopter is affine in its controls)
+    (f, f_x, f_u), (c, c_x, c_u, c_xx, c_ux, c_uu), (v, v_x, v_xx) = problems.random_ilqr_model(b, T, n, m, seed=43)
+    dev = [torch.as_tensor(np.ascontiguousarray(X), device="cuda") for X in (f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, v_x, v_xx)]
+    l1, L1 = torch.empty((b, T, m), dtype=torch.float64, device="cuda"), torch.empty((b, T, m, n), dtype=torch.float64, device="cuda")
+    l2, L2 = torch.empty_like(l1), torch.empty_like(L1)
+    _lib.check(lib.zm_ddp_backward_f64(dev[0].data_ptr(), dev[1].data_ptr(), f_xx.data_ptr(), None, None, *[t.data_ptr() for t in dev[2:]],
+                                       None, 0, l1.data_ptr(), L1.data_ptr(), b, T, n, m, st), "full sweep")
+    _lib.check(lib.zm_ddp_backward_pairs_list_f64(pmd, dev[0].data_ptr(), dev[1].data_ptr(), H.data_ptr(), *[t.data_ptr() for t in dev[2:]],
+                                                  None, 0, None, 0, l2.data_ptr(), L2.data_ptr(), b, T, st), "packed sweep")
+    assert torch.equal(l1, l2) and torch.equal(L1, L2)
+    # a model without declared pairs is refused, not mis-read
+    lin = models.LinearModel(np.eye(2), np.eye(2)).c_struct()
+    assert lib.zm_quadratic_dynamics_pairs_list_f64(ctypes.addressof(lin), xT.data_ptr(), uT.data_ptr(), None, 0, None, H.data_ptr(), 1, 1,
+                                                    st) == _lib.ZM_EUNSUPPORTED

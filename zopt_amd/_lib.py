@@ -91,6 +91,18 @@ SYMBOLS = {
                                     [_c_dp] * 10 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "zm_quadratic_dynamics_list_f64": (ctypes.c_int, [_c_dp] * 4 + [ctypes.c_int64] + [_c_dp] * 4 +
                                        [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "zm_model_hessian_pairs": (ctypes.c_int, [_c_dp, _c_dp, _c_dp]),
+    # (model*, xTraj, uTraj, list, count, active, H, batch, T, stream)
+    "zm_quadratic_dynamics_pairs_list_f64": (ctypes.c_int, [_c_dp] * 4 + [ctypes.c_int64] + [_c_dp] * 2 +
+                                             [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    # (model*, f_x, f_u, H, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, list, count, active, shared_hessian, l, L, batch, T, stream)
+    "zm_ddp_backward_pairs_list_f64": (ctypes.c_int, [_c_dp] * 12 + [ctypes.c_int64, _c_dp, ctypes.c_int] + [_c_dp] * 2 +
+                                       [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "zm_ilqr_solve_workspace_f64": (ctypes.c_int64, [_c_dp, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    # (model*, cost*, x0, uGuess, ddp, max_iter, tol, sync_every, workspace, workspace_doubles, iwork, xTraj, uTraj, L, J, converged,
+    #  iterations (host), batch, T, stream)
+    "zm_ilqr_solve_f64": (ctypes.c_int, [_c_dp] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, _c_dp, ctypes.c_int64] +
+                          [_c_dp] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "zm_model_nonlinear_mask": (ctypes.c_int, [_c_dp, _c_dp]),
     "zm_psd_project_f64": (ctypes.c_int, [_c_dp, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
     "zm_condition_cost_f64": (ctypes.c_int, [_c_dp] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double,

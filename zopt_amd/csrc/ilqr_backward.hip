@@ -37,6 +37,7 @@
 // nonsymmetric V is treated exactly as the reference does.
 #include "dma_ring.h"
 #include "jacobi16.h"
+#include "models.h"
 #include "ns16.h"
 #include "tile16_f64.h"
 #include "zm_common.h"
@@ -312,7 +313,8 @@ __global__ __launch_bounds__(64, 2) void ilqr_backward_t16_f64(
     const double* __restrict__ f_uu, const long svx, const long svxx, const int* __restrict__ active,
     const int shared_h, double* __restrict__ lout, double* __restrict__ Lout, const int T, const int n, const int m,
     const double* __restrict__ c_s, const double* __restrict__ vf_s, double* __restrict__ v_out,
-    double* __restrict__ vx_out, double* __restrict__ vxx_out, const TrajList tl) {
+    double* __restrict__ vx_out, double* __restrict__ vxx_out, const TrajList tl, const double* __restrict__ Hpk,
+    const PairTab ptab) {
     constexpr int NP = 4 * KS;
     const int lane = threadIdx.x;
     const long traj = tl.list ? (long)tl.list[blockIdx.x] : (long)blockIdx.x;
@@ -384,7 +386,23 @@ __global__ __launch_bounds__(64, 2) void ilqr_backward_t16_f64(
             const int cb = cA ? c : (cB ? n + (c - NP) : -1);
             a.zc[r] = (ca >= 0 && cb >= 0) ? ca * PLD + cb : -1;
             a.zlive[r] = (ca >= 0) && (row == c);
-            if (f_ux == nullptr && !(rx && cA)) {   // dynamics affine in the controls: f_ux, f_uu are zero and not materialised
+            if (Hpk != nullptr) {
+                // packed second derivatives (zm_quadratic_dynamics_pairs_list_f64): element (ca, cb) is pair p = (min, max) of the
+                // model's table or structurally zero; H[pt][p][i], i contiguous -> the contraction below runs unchanged with a
+                // unit stride over i and the same summation order as over the full tensors
+                int pidx = -1;
+                if (ca >= 0 && cb >= 0) {
+                    const int lo = ca < cb ? ca : cb, hi = ca < cb ? cb : ca;
+                    for (int q = 0; q < ptab.n; ++q) pidx = (ptab.ab[q] == (unsigned char)(lo * 16 + hi)) ? q : pidx;
+                }
+                const double* Hl = Hpk + last * (long)ptab.n * n;
+                if (pidx >= 0) {
+                    a.pz[r] = Hl + (long)pidx * n;  a.sz[r] = 1;  a.stz[r] = ptab.n * n;
+                } else {   // structurally zero (or padding): the lane contracts don't-care data and contributes an exact 0.0
+                    a.pz[r] = Hl;  a.sz[r] = 0;  a.stz[r] = ptab.n * n;
+                    a.zc[r] = -1;
+                }
+            } else if (f_ux == nullptr && !(rx && cA)) {   // dynamics affine in the controls: f_ux, f_uu are zero and not materialised
                 a.zc[r] = -1;
                 a.pz[r] = fxxt;  a.sz[r] = 0;  a.stz[r] = (int)nnn;
             } else if (rx && cA) {     // f_xx[i][row][c]
@@ -707,6 +725,8 @@ static int ilqr_backward_dma_dispatch(const double* f_x, const double* f_u, cons
 namespace zm {
 struct DdpTensors {
     const double *f_xx, *f_ux, *f_uu;
+    const double* Hpk = nullptr;   // packed second derivatives of the model's declared pairs (instead of the three tensors)
+    PairTab ptab = PairTab{};
 };
 struct ValueIO {   // optional scalar inputs / value-function outputs
     const double *c, *vf;
@@ -722,13 +742,13 @@ static int launch_ilqr(const double* f_x, const double* f_u, const double* c_x, 
     const dim3 grid((unsigned)(tl.list ? tl.count : batch)), block(64);
     if (n <= 4)
         hipLaunchKernelGGL((ilqr_backward_t16_f64<1, MODE>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
-                           vf_xx, d, z.f_xx, z.f_ux, z.f_uu, svx, svxx, act, sh, l, L, T, n, m, v.c, v.vf, v.v_out, v.vx_out, v.vxx_out, tl);
+                           vf_xx, d, z.f_xx, z.f_ux, z.f_uu, svx, svxx, act, sh, l, L, T, n, m, v.c, v.vf, v.v_out, v.vx_out, v.vxx_out, tl, z.Hpk, z.ptab);
     else if (n <= 8)
         hipLaunchKernelGGL((ilqr_backward_t16_f64<2, MODE>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
-                           vf_xx, d, z.f_xx, z.f_ux, z.f_uu, svx, svxx, act, sh, l, L, T, n, m, v.c, v.vf, v.v_out, v.vx_out, v.vxx_out, tl);
+                           vf_xx, d, z.f_xx, z.f_ux, z.f_uu, svx, svxx, act, sh, l, L, T, n, m, v.c, v.vf, v.v_out, v.vx_out, v.vxx_out, tl, z.Hpk, z.ptab);
     else
         hipLaunchKernelGGL((ilqr_backward_t16_f64<3, MODE>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
-                           vf_xx, d, z.f_xx, z.f_ux, z.f_uu, svx, svxx, act, sh, l, L, T, n, m, v.c, v.vf, v.v_out, v.vx_out, v.vxx_out, tl);
+                           vf_xx, d, z.f_xx, z.f_ux, z.f_uu, svx, svxx, act, sh, l, L, T, n, m, v.c, v.vf, v.v_out, v.vx_out, v.vxx_out, tl, z.Hpk, z.ptab);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }
@@ -817,6 +837,31 @@ extern "C" int zm_ddp_backward_list_f64(const double* f_x, const double* f_u, co
                               (const int*)active, shared_hessian ? 1 : 0, l, L, batch, T, n, m, (hipStream_t)stream,
                               zm::DdpTensors{f_xx, f_ux, f_uu}, zm::ValueIO{nullptr, nullptr, nullptr, nullptr, nullptr},
                               zm::TrajList{(const int*)list, (long)count});
+}
+
+extern "C" int zm_ddp_backward_pairs_list_f64(const zm_model_t* model, const double* f_x, const double* f_u, const double* H,
+                                              const double* c_x, const double* c_u, const double* c_xx, const double* c_ux,
+                                              const double* c_uu, const double* vf_x, const double* vf_xx, const int32_t* list,
+                                              int64_t count, const int32_t* active, int shared_hessian, double* l, double* L,
+                                              int64_t batch, int T, void* stream) {
+    if (batch == 0 || (list && count == 0)) return ZM_OK;
+    if (list && (count < 0 || count > batch)) return zm::set_error(ZM_EINVAL, "zm_ddp_backward_pairs_list_f64: bad list length");
+    if (!model || !f_x || !f_u || !H || !c_x || !c_u || !c_xx || !c_ux || !c_uu || !vf_x || !vf_xx || !l || !L)
+        return zm::set_error(ZM_EINVAL, "zm_ddp_backward_pairs_list_f64: null pointer");
+#ifdef ZM_DDP_PSD_JACOBI
+    return zm::set_error(ZM_EUNSUPPORTED, "zm_ddp_backward_pairs_list_f64: not available in the Jacobi-projection build");
+#endif
+    const int n = model->n, m = model->m;
+    const int rc = zm_check_sweep_args("zm_ddp_backward_pairs_list_f64", batch, T, n, m);
+    if (rc) return rc;
+    const zm::PairTab pt = zm::model_pair_table(model->kind);
+    if (pt.n < 1)
+        return zm::set_error(ZM_EUNSUPPORTED, "zm_ddp_backward_pairs_list_f64: the model declares no Hessian pairs");
+    const zm::TrajList tl{(const int*)list, (long)count};
+    zm::DdpTensors z{nullptr, nullptr, nullptr, H, pt};
+    return zm::launch_ilqr<2>(f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, (long)n, (long)n * n, (const int*)active,
+                              shared_hessian ? 1 : 0, l, L, batch, T, n, m, (hipStream_t)stream, z,
+                              zm::ValueIO{nullptr, nullptr, nullptr, nullptr, nullptr}, tl);
 }
 
 extern "C" int zm_ddp_backward_f64(const double* f_x, const double* f_u, const double* f_xx, const double* f_ux,

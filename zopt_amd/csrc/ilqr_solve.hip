@@ -1,0 +1,205 @@
+// K8  ilqr_solve -- the iLQR / DDP outer loop as ONE C-ABI call: the host side of the iteration (launch sequence, compacted
+// list of still-active trajectories, termination test) runs here in C++ instead of in Python.
+//
+// Replaces: zopt/ilqrUtils.py:290-327 (iterativeLqr) and :360-397 (differentialDynamicProgramming), per trajectory
+//     policy = (uGuess, 0); traj = rollout(x0, policy, zeros); J = cost(traj)                                   (:293-298)
+//     while not converged and it < maxIter:                                                                      (:301-303)
+//         expansions along traj; PD-conditioned Hessians; backward pass; 16-way line search; converged = |J - Jn| <= tol
+// on a batch: every kernel runs over the compacted id list of the trajectories that have not converged yet (rebuilt on the
+// device every `sync_every` iterations, when the host also learns how many are left), converged trajectories drop out.
+// The kernels are the ones behind the array-level entry points (linearize.hip, ilqr_backward.hip, rollout*.hip, psd.hip);
+// nothing is allocated here: the caller provides the workspace (zm_ilqr_solve_workspace_f64 tells how much).
+#include <cstdint>
+
+#include "zm_common.h"
+
+namespace zm {
+
+// Stable compaction of the active ids (ascending trajectory order, as torch.nonzero gave the Python loop): one block, one
+// ballot-scan pass per 1024 trajectories.  count[0] <- number of active trajectories.
+__global__ __launch_bounds__(1024) void compact_active_kernel(const int* __restrict__ active, const long batch, int* __restrict__ list,
+                                                              int* __restrict__ count) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (long start = 0; start < batch; start += 1024) {
+        const long i = start + tid;
+        const bool a = i < batch && active[i] != 0;
+        const unsigned long long m = __ballot(a);
+        const int before = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[w] = __builtin_popcountll(m);
+        __syncthreads();
+        int off = base;
+        for (int j = 0; j < w; ++j) off += wsum[j];
+        if (a) list[off + before] = (int)i;
+        __syncthreads();
+        if (tid == 0) {
+            int s = 0;
+            for (int j = 0; j < 16; ++j) s += wsum[j];
+            base += s;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) count[0] = base;
+}
+
+__global__ void fill_i32_kernel(int* __restrict__ p, const long n, const int v) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__global__ void fill_f64_kernel(double* __restrict__ p, const long n, const double v) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+struct IlqrWs {   // carve of the caller's workspace (doubles)
+    long l, xT2, uT2, Jn, f_x, f_u, c_x, c_u, v_x, c_xx, c_ux, c_uu, v_xx, alphas, f_xx, f_ux, f_uu, total;
+};
+
+static IlqrWs carve(long b, long T, long n, long m, int ddp, int need_ux, int npairs) {
+    IlqrWs w;
+    long o = 0;
+    auto take = [&](long cnt) {
+        const long at = o;
+        o += (cnt + 1) & ~1L;   // 16-B aligned pieces (the sweep kernels' DMA path needs it)
+        return at;
+    };
+    w.l = take(b * T * m);
+    w.xT2 = take(b * (T + 1) * n);
+    w.uT2 = take(b * T * m);
+    w.Jn = take(b);
+    w.f_x = take(b * T * n * n);
+    w.f_u = take(b * T * n * m);
+    w.c_x = take(b * T * n);
+    w.c_u = take(b * T * m);
+    w.v_x = take(b * n);
+    w.c_xx = take(n * n);
+    w.c_ux = take(m * n);
+    w.c_uu = take(m * m);
+    w.v_xx = take(n * n);
+    w.alphas = take(16);
+    // second derivatives: packed (pairs x n per point) when the model declares its nonzero pairs, else the full tensors
+    w.f_xx = ddp ? take(npairs > 0 ? b * T * npairs * n : b * T * n * n * n) : 0;
+    w.f_ux = (ddp && need_ux && npairs == 0) ? take(b * T * n * m * n) : 0;
+    w.f_uu = (ddp && need_ux && npairs == 0) ? take(b * T * n * m * m) : 0;
+    w.total = o;
+    return w;
+}
+
+}  // namespace zm
+
+extern "C" int64_t zm_ilqr_solve_workspace_f64(const zm_model_t* model, int64_t batch, int T, int ddp) {
+    if (!model || batch < 0 || T < 1) return -1;
+    uint32_t mask = 0;
+    int32_t npairs = 0;
+    if (ddp && (zm_model_nonlinear_mask(model, &mask) != ZM_OK || zm_model_hessian_pairs(model, nullptr, &npairs) != ZM_OK)) return -1;
+    return zm::carve(batch, T, model->n, model->m, ddp, (mask >> model->n) != 0, npairs).total;
+}
+
+extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0, const double* uGuess,
+                                 int ddp, int max_iter, double tol, int sync_every, double* workspace, int64_t workspace_doubles,
+                                 int32_t* iwork, double* xTraj, double* uTraj, double* L, double* J, int32_t* converged,
+                                 int32_t* iterations, int64_t batch, int T, void* stream) {
+    if (batch == 0) return ZM_OK;
+    if (!model || !cost || !x0 || !uGuess || !workspace || !iwork || !xTraj || !uTraj || !L || !J || !converged)
+        return zm::set_error(ZM_EINVAL, "zm_ilqr_solve_f64: null pointer");
+    if (batch < 0 || T < 1 || max_iter < 0 || sync_every < 1) return zm::set_error(ZM_EINVAL, "zm_ilqr_solve_f64: bad size");
+    const int n = model->n, m = model->m;
+    uint32_t mask = 0;
+    int32_t npairs = 0;
+    if (ddp) {
+        int rc = zm_model_nonlinear_mask(model, &mask);
+        if (rc) return rc;
+        rc = zm_model_hessian_pairs(model, nullptr, &npairs);
+        if (rc) return rc;
+    }
+    const int need_ux = (mask >> n) != 0;   // a model affine in its controls has f_ux = f_uu = 0: neither written nor read
+    const zm::IlqrWs w = zm::carve(batch, T, n, m, ddp, need_ux, npairs);
+    if (workspace_doubles < w.total)
+        return zm::set_error(ZM_EINVAL, "zm_ilqr_solve_f64: workspace of %lld doubles, %lld needed", (long long)workspace_doubles,
+                             (long long)w.total);
+    hipStream_t st = (hipStream_t)stream;
+    double* ws = workspace;
+    // iwork (int32): active (batch) | list (batch) | count (2)
+    int32_t* active = iwork;
+    int32_t* list = iwork + batch;
+    int32_t* dcount = iwork + 2 * batch;
+    const long xrow = (long)(T + 1) * n, urow = (long)T * m;
+
+    // policy = (uGuess, 0); traj_prev = zeros                                                        (ilqrUtils.py:293-294)
+    ZM_HIP_CHECK(hipMemcpyAsync(ws + w.l, uGuess, sizeof(double) * batch * urow, hipMemcpyDeviceToDevice, st));
+    ZM_HIP_CHECK(hipMemsetAsync(L, 0, sizeof(double) * batch * urow * n, st));
+    ZM_HIP_CHECK(hipMemsetAsync(ws + w.xT2, 0, sizeof(double) * batch * xrow, st));
+    ZM_HIP_CHECK(hipMemsetAsync(ws + w.uT2, 0, sizeof(double) * batch * urow, st));
+    {
+        double h_alpha[16];
+        for (int j = 0; j < 16; ++j) h_alpha[j] = 1.0 / (double)(1u << j);   // 0.5 ** arange(16)          (:145)
+        ZM_HIP_CHECK(hipMemcpyAsync(ws + w.alphas, h_alpha, sizeof(h_alpha), hipMemcpyHostToDevice, st));
+        ZM_HIP_CHECK(hipStreamSynchronize(st));   // h_alpha is a stack buffer
+    }
+    hipLaunchKernelGGL(zm::fill_i32_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, active, (long)batch, 1);
+    ZM_HIP_CHECK(hipMemsetAsync(converged, 0, sizeof(int32_t) * batch, st));
+    // initial rollout (alpha = 1) from the zero trajectory and its cost                                (:297-298)
+    int rc = zm_rollout_linesearch_f64(model, cost, x0, ws + w.l, L, ws + w.xT2, ws + w.uT2, ws + w.alphas, 1, nullptr, xTraj, uTraj, J,
+                                       nullptr, batch, T, st);
+    if (rc) return rc;
+    // trajectory-independent Hessians of the quadratic cost, PD-conditioned once                         (:309-313)
+    rc = zm_quadratize_cost_f64(cost, n, m, xTraj, uTraj, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws + w.c_xx,
+                                ws + w.c_ux, ws + w.c_uu, ws + w.v_xx, 0, T, st);
+    if (rc) return rc;
+    rc = zm_condition_cost_f64(ws + w.c_xx, ws + w.c_ux, ws + w.c_uu, 1, n, m, 1e-3, st);
+    if (rc) return rc;
+    rc = zm_psd_project_f64(ws + w.v_xx, 1, n, 1e-3, st);
+    if (rc) return rc;
+
+    double* f_ux = (need_ux && npairs == 0) ? ws + w.f_ux : nullptr;
+    double* f_uu = (need_ux && npairs == 0) ? ws + w.f_uu : nullptr;
+    int it = 0;
+    int64_t count = batch;
+    for (; it < max_iter; ++it) {                                                                        // (:301-303)
+        if (it % sync_every == 0) {   // rebuild the id list on the device, learn how many trajectories are left
+            hipLaunchKernelGGL(zm::compact_active_kernel, dim3(1), dim3(1024), 0, st, (const int*)active, (long)batch, (int*)list,
+                               (int*)dcount);
+            int32_t hcount = 0;
+            ZM_HIP_CHECK(hipMemcpyAsync(&hcount, dcount, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            ZM_HIP_CHECK(hipStreamSynchronize(st));
+            count = hcount;
+            if (count == 0) break;
+        }
+        rc = zm_linearize_dynamics_list_f64(model, xTraj, uTraj, list, count, active, nullptr, ws + w.f_x, ws + w.f_u, batch, T, st);
+        if (rc) return rc;
+        rc = zm_quadratize_cost_list_f64(cost, n, m, xTraj, uTraj, list, count, active, nullptr, ws + w.c_x, ws + w.c_u, nullptr,
+                                         ws + w.v_x, nullptr, nullptr, nullptr, nullptr, batch, T, st);
+        if (rc) return rc;
+        if (ddp && npairs > 0) {
+            // packed second derivatives: 28 x 12 doubles per point for the quadcopter instead of the zero-filled (n,n,n) tensors
+            // (2.7 KB instead of 13.8 KB written by the expansion and read back by the sweep, same arithmetic)
+            rc = zm_quadratic_dynamics_pairs_list_f64(model, xTraj, uTraj, list, count, active, ws + w.f_xx, batch, T, st);
+            if (rc) return rc;
+            rc = zm_ddp_backward_pairs_list_f64(model, ws + w.f_x, ws + w.f_u, ws + w.f_xx, ws + w.c_x, ws + w.c_u, ws + w.c_xx,
+                                                ws + w.c_ux, ws + w.c_uu, ws + w.v_x, ws + w.v_xx, list, count, active, 1, ws + w.l,
+                                                L, batch, T, st);
+        } else if (ddp) {
+            rc = zm_quadratic_dynamics_list_f64(model, xTraj, uTraj, list, count, active, ws + w.f_xx, f_ux, f_uu, batch, T, st);
+            if (rc) return rc;
+            rc = zm_ddp_backward_list_f64(ws + w.f_x, ws + w.f_u, ws + w.f_xx, f_ux, f_uu, ws + w.c_x, ws + w.c_u, ws + w.c_xx,
+                                          ws + w.c_ux, ws + w.c_uu, ws + w.v_x, ws + w.v_xx, list, count, active, 1, ws + w.l, L,
+                                          batch, T, n, m, st);
+        } else {
+            rc = zm_ilqr_backward_list_f64(ws + w.f_x, ws + w.f_u, ws + w.c_x, ws + w.c_u, ws + w.c_xx, ws + w.c_ux, ws + w.c_uu,
+                                           ws + w.v_x, ws + w.v_xx, list, count, active, 1, ws + w.l, L, batch, T, n, m, st);
+        }
+        if (rc) return rc;
+        rc = zm_rollout_linesearch_list_f64(model, cost, x0, ws + w.l, L, xTraj, uTraj, ws + w.alphas, 16, list, count, active,
+                                            ws + w.xT2, ws + w.uT2, ws + w.Jn, nullptr, batch, T, st);
+        if (rc) return rc;
+        // accept: converged = |J - J_new| <= tol, (traj, J) <- (traj_new, J_new) on the listed rows        (:316-320)
+        rc = zm_ilqr_accept_f64(list, count, J, ws + w.Jn, xTraj, ws + w.xT2, uTraj, ws + w.uT2, converged, active, tol, batch, T, n,
+                                m, st);
+        if (rc) return rc;
+    }
+    if (iterations) *iterations = it;
+    return ZM_OK;
+}

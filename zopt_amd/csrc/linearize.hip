@@ -144,6 +144,45 @@ __global__ __launch_bounds__(64) void quadratic_dynamics_kernel(const zm_model_t
     }
 }
 
+// The same second derivatives PACKED: H[pt][p][i] = d2 f_i / dz_a dz_b for the model's declared pairs p = (a <= b) only -- every
+// other entry of f_xx / f_ux / f_uu is structurally zero.  The quadcopter: 28 x 12 doubles = 2 688 B per trajectory point instead of
+// 19 968 B (13 824 B without the control blocks), all of it written by coalesced stores, nothing zero-filled.  Consumed by the
+// DDP sweep (zm_ddp_backward_pairs_list_f64), whose contraction sum_i v_x[i] H[p][i] runs in the same order as over the full
+// tensors: bitwise the same result.
+template <int PPW>
+__global__ __launch_bounds__(64) void quadratic_dynamics_pairs_kernel(const zm_model_t md, const double* __restrict__ xTraj,
+                                                                      const double* __restrict__ uTraj,
+                                                                      const int* __restrict__ active, double* __restrict__ H,
+                                                                      const long batch, const int T,
+                                                                      const int* __restrict__ list, const long count) {
+    constexpr int LPP = 64 / PPW;                       // lanes per point
+    const int sub = threadIdx.x / LPP, lp = threadIdx.x % LPP;
+    const long nslot = list ? count : batch;
+    const long sp = (long)blockIdx.x * PPW + sub;       // slot * T + k
+    if (sp >= nslot * T) return;
+    const long slot = sp / T;
+    const int k = (int)(sp - slot * T);
+    const long traj = list ? (long)list[slot] : slot;
+    if (active && active[traj] == 0) return;
+    const long pt = traj * T + k;
+    const int n = md.n, m = md.m;
+    const double* xk = xTraj + (traj * (T + 1) + k) * n;
+    const double* uk = uTraj + pt * m;
+    int a = 0, b = 0;
+    const int npairs = model_hessian_pairs(md, lp, a, b);
+    if (lp >= npairs) return;
+    double* o = H + (pt * npairs + lp) * n;
+    Hyper x[MAXN], u[MAXM], xn[MAXN];
+#pragma unroll
+    for (int i = 0; i < MAXN; ++i) x[i] = Hyper{(i < n) ? xk[i] : 0.0, (i == a) ? 1.0 : 0.0, (i == b) ? 1.0 : 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < MAXM; ++i) u[i] = Hyper{(i < m) ? uk[i] : 0.0, (n + i == a) ? 1.0 : 0.0, (n + i == b) ? 1.0 : 0.0, 0.0};
+    model_step<Hyper>(md, x, u, xn);
+#pragma unroll
+    for (int i = 0; i < MAXN; ++i)
+        if (i < n) o[i] = xn[i].d12;
+}
+
 // one thread per (trajectory, step) point plus one per trajectory for the terminal expansion
 __global__ __launch_bounds__(256) void quadratize_cost_kernel(const zm_quadcost_t cs, const int n, const int m,
                                                               const double* __restrict__ xTraj,
@@ -333,6 +372,42 @@ extern "C" int zm_quadratic_dynamics_list_f64(const zm_model_t* model, const dou
     else
         hipLaunchKernelGGL(zm::quadratic_dynamics_kernel<1>, dim3((unsigned)npts), dim3(64), 0, (hipStream_t)stream, md, xTraj,
                            uTraj, (const int*)active, f_xx, f_ux, f_uu, (long)batch, T, (const int*)list, (long)count);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+
+extern "C" int zm_model_hessian_pairs(const zm_model_t* model, int32_t* pairs, int32_t* npairs) {
+    zm_model_t md;
+    const int rc = zm_check_model(model, md, "zm_model_hessian_pairs");
+    if (rc) return rc;
+    if (!npairs) return zm::set_error(ZM_EINVAL, "zm_model_hessian_pairs: null pointer");
+    const zm::PairTab t = zm::model_pair_table(md.kind);
+    *npairs = t.n;
+    if (pairs)
+        for (int q = 0; q < t.n; ++q) {
+            pairs[2 * q] = t.ab[q] >> 4;
+            pairs[2 * q + 1] = t.ab[q] & 15;
+        }
+    return ZM_OK;
+}
+
+extern "C" int zm_quadratic_dynamics_pairs_list_f64(const zm_model_t* model, const double* xTraj, const double* uTraj,
+                                                    const int32_t* list, int64_t count, const int32_t* active, double* H,
+                                                    int64_t batch, int T, void* stream) {
+    if (batch == 0 || (list && count == 0)) return ZM_OK;
+    zm_model_t md;
+    int rc = zm_check_model(model, md, "zm_quadratic_dynamics_pairs_list_f64");
+    if (rc) return rc;
+    if (!xTraj || !uTraj || !H) return zm::set_error(ZM_EINVAL, "zm_quadratic_dynamics_pairs_list_f64: null pointer");
+    if (batch < 0 || T < 1) return zm::set_error(ZM_EINVAL, "zm_quadratic_dynamics_pairs_list_f64: bad size");
+    if ((rc = zm_check_list("zm_quadratic_dynamics_pairs_list_f64", list, count, batch))) return rc;
+    const int np = zm::model_pair_table(md.kind).n;
+    if (np < 1 || np > 32)
+        return zm::set_error(ZM_EUNSUPPORTED, "zm_quadratic_dynamics_pairs_list_f64: the model declares no Hessian pairs "
+                                              "(zm_model_hessian_pairs); use zm_quadratic_dynamics_list_f64");
+    const long npts = (list ? (long)count : (long)batch) * T;
+    hipLaunchKernelGGL(zm::quadratic_dynamics_pairs_kernel<2>, dim3((unsigned)((npts + 1) / 2)), dim3(64), 0, (hipStream_t)stream, md,
+                       xTraj, uTraj, (const int*)active, H, (long)batch, T, (const int*)list, (long)count);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }

@@ -175,6 +175,22 @@ __host__ __device__ __forceinline__ unsigned model_nonlinear_mask(const zm_model
 // rotation).  28 pairs instead of 45: two trajectory points share a wave.  tests/test_ddp_gpu.py checks against autograd that
 // every other second derivative is exactly zero.
 constexpr int ZM_MAX_PAIRS = 32;
+// The same table by value (host and device): ab[p] = a * 16 + b, n pairs (0: the model declares none).  Kernels that consume
+// the packed second derivatives of zm_quadratic_dynamics_pairs_list_f64 take it as an argument.
+struct PairTab {
+    int n;
+    unsigned char ab[ZM_MAX_PAIRS];
+};
+__host__ __device__ inline PairTab model_pair_table(const int kind) {
+    PairTab t{};
+    if (kind == ZM_MODEL_QUADCOPTER) {
+        const unsigned char tab[28] = {0x00, 0x11, 0x22, 0x24, 0x15, 0x05, 0x23, 0x13, 0x04, 0x66, 0x67, 0x77, 0x68, 0x78,
+                                       0x88, 0x06, 0x07, 0x08, 0x16, 0x17, 0x18, 0x26, 0x27, 0x28, 0x46, 0x47, 0x56, 0x57};
+        t.n = 28;
+        for (int q = 0; q < 28; ++q) t.ab[q] = tab[q];
+    }
+    return t;
+}
 __device__ __forceinline__ int model_hessian_pairs(const zm_model_t& md, const int p, int& a, int& b) {
     if (md.kind == ZM_MODEL_QUADCOPTER) {
         // packed as a * 16 + b

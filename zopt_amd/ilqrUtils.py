@@ -136,6 +136,7 @@ def riccatiStep_ddp(dynamics, cost, value):
 
 
 LINESEARCH_ALPHAS = 0.5 ** np.arange(16)   # reference ilqrUtils.py:145
+_TRACE = None   # diagnostics: a list that receives (iteration, active trajectories) at every host synchronisation
 
 
 def _rollout(x0, dynFun, policy, trajPrev, alphas, costFun):
@@ -361,101 +362,36 @@ def _ilqr_or_ddp(dynamics, runningCost, terminalCost, x0, uGuess, maxIter, tol, 
     dt = torch.float64
     lib = _lib.lib()
     dx0 = arr.to_device(x0, dt).reshape(-1, n).contiguous()
-    l = arr.to_device(uGuess, dt).reshape(-1, N, m).clone()          # policy = (uGuess, 0)          (:293)
+    dug = arr.to_device(uGuess, dt).reshape(-1, N, m).contiguous()
     dev = dx0.device
     B = dx0.shape[0]
     st = ctypes.c_void_p(arr.stream_ptr(dx0))
-    L = torch.zeros((B, N, m, n), dtype=dt, device=dev)
-    xT = torch.zeros((B, N + 1, n), dtype=dt, device=dev)            # traj_prev = zeros               (:294)
-    uT = torch.zeros((B, N, m), dtype=dt, device=dev)
-    xT2, uT2 = torch.empty_like(xT), torch.empty_like(uT)
-    J, Jn = torch.empty(B, dtype=dt, device=dev), torch.empty(B, dtype=dt, device=dev)
     md, cs = model.c_struct(), cost.c_struct()
     pmd, pcs = ctypes.addressof(md), ctypes.addressof(cs)
-    one = torch.ones(1, dtype=dt, device=dev)
-    alphas = torch.as_tensor(LINESEARCH_ALPHAS, dtype=dt, device=dev)
-
-    # initial rollout (alpha = 1) and its cost                                                       (:297-298)
-    _lib.check(lib.zm_rollout_linesearch_f64(pmd, pcs, dx0.data_ptr(), l.data_ptr(), L.data_ptr(), xT.data_ptr(),
-                                             uT.data_ptr(), one.data_ptr(), 1, None, xT2.data_ptr(), uT2.data_ptr(),
-                                             J.data_ptr(), None, B, N, st), "iterativeLqr: initial rollout")
-    xT, xT2 = xT2, xT
-    uT, uT2 = uT2, uT
-
-    # trajectory-independent Hessians of the quadratic cost, PD-conditioned once                     (:309-313)
-    c_xx = torch.empty((n, n), dtype=dt, device=dev)
-    c_ux = torch.empty((m, n), dtype=dt, device=dev)
-    c_uu = torch.empty((m, m), dtype=dt, device=dev)
-    v_xx = torch.empty((n, n), dtype=dt, device=dev)
-    _lib.check(lib.zm_quadratize_cost_f64(pcs, n, m, xT.data_ptr(), uT.data_ptr(), None, None, None, None, None, None,
-                                          c_xx.data_ptr(), c_ux.data_ptr(), c_uu.data_ptr(), v_xx.data_ptr(), 0, N, st),
-               "iterativeLqr: cost Hessians")
-    _lib.check(lib.zm_condition_cost_f64(c_xx.data_ptr(), c_ux.data_ptr(), c_uu.data_ptr(), 1, n, m, 1e-3, st),
-               "iterativeLqr: conditionQuadraticCost")
-    _lib.check(lib.zm_psd_project_f64(v_xx.data_ptr(), 1, n, 1e-3, st), "iterativeLqr: conditionValueFunction")
-
-    f_x = torch.empty((B, N, n, n), dtype=dt, device=dev)
-    f_u = torch.empty((B, N, n, m), dtype=dt, device=dev)
-    c_x = torch.empty((B, N, n), dtype=dt, device=dev)
-    c_u = torch.empty((B, N, m), dtype=dt, device=dev)
-    v_x = torch.empty((B, n), dtype=dt, device=dev)
-    if ddp:
-        f_xx = torch.empty((B, N, n, n, n), dtype=dt, device=dev)
-        # a model that is affine in its controls has f_ux = f_uu = 0: neither written nor read (zm_model_nonlinear_mask)
-        nl_mask = ctypes.c_uint32(0)
-        _lib.check(lib.zm_model_nonlinear_mask(pmd, ctypes.byref(nl_mask)), "DDP: model structure")
-        if (nl_mask.value >> n) == 0:
-            f_ux = f_uu = None
-        else:
-            f_ux = torch.empty((B, N, n, m, n), dtype=dt, device=dev)
-            f_uu = torch.empty((B, N, n, m, m), dtype=dt, device=dev)
-        p_ux = f_ux.data_ptr() if f_ux is not None else None
-        p_uu = f_uu.data_ptr() if f_uu is not None else None
+    L = torch.empty((B, N, m, n), dtype=dt, device=dev)
+    xT = torch.empty((B, N + 1, n), dtype=dt, device=dev)
+    uT = torch.empty((B, N, m), dtype=dt, device=dev)
+    J = torch.empty(B, dtype=dt, device=dev)
     converged = torch.zeros(B, dtype=torch.int32, device=dev)
-    active = torch.ones(B, dtype=torch.int32, device=dev)
-    it = 0
-    ids = None
-    # host synchronisation (termination test + rebuild of the compacted id list) every SYNC iterations; in between the kernels run
-    # on the device-side mask alone -- an iteration over a fully converged batch touches nothing, so the results do not depend on
-    # SYNC (measured: 78.5 ms per 8192-problem iLQR solve with 1, 74.7 ms with 4 or 8)
-    SYNC = max(1, int(os.environ.get("ZOPT_AMD_ILQR_SYNC", "4")))
-    while it < maxIter:                                                                               # (:301-303)
-        if it % SYNC == 0:
-            if not bool(active.any()):
-                break
-            ids = torch.nonzero(active).flatten().to(torch.int32)
-        ap = active.data_ptr()
-        # the expansions run over the compacted id list as the line search does: with a mask alone their grids would stay at the
-        # full batch (late iterations: ~100 us of early-exiting blocks per iteration)
-        ip, ic = ids.data_ptr(), int(ids.numel())
-        _lib.check(lib.zm_linearize_dynamics_list_f64(pmd, xT.data_ptr(), uT.data_ptr(), ip, ic, ap, None, f_x.data_ptr(),
-                                                      f_u.data_ptr(), B, N, st), "iterativeLqr: linearize")
-        _lib.check(lib.zm_quadratize_cost_list_f64(pcs, n, m, xT.data_ptr(), uT.data_ptr(), ip, ic, ap, None, c_x.data_ptr(),
-                                                   c_u.data_ptr(), None, v_x.data_ptr(), None, None, None, None, B, N, st),
-                   "iterativeLqr: quadratize")
-        if ddp:
-            _lib.check(lib.zm_quadratic_dynamics_list_f64(pmd, xT.data_ptr(), uT.data_ptr(), ip, ic, ap, f_xx.data_ptr(),
-                                                          p_ux, p_uu, B, N, st), "DDP: quadratic dynamics")
-            _lib.check(lib.zm_ddp_backward_list_f64(f_x.data_ptr(), f_u.data_ptr(), f_xx.data_ptr(), p_ux,
-                                                    p_uu, c_x.data_ptr(), c_u.data_ptr(), c_xx.data_ptr(),
-                                                    c_ux.data_ptr(), c_uu.data_ptr(), v_x.data_ptr(), v_xx.data_ptr(), ip, ic, ap, 1,
-                                                    l.data_ptr(), L.data_ptr(), B, N, n, m, st), "DDP: backward pass")
-        else:
-            _lib.check(lib.zm_ilqr_backward_list_f64(f_x.data_ptr(), f_u.data_ptr(), c_x.data_ptr(), c_u.data_ptr(),
-                                                     c_xx.data_ptr(), c_ux.data_ptr(), c_uu.data_ptr(), v_x.data_ptr(),
-                                                     v_xx.data_ptr(), ip, ic, ap, 1, l.data_ptr(), L.data_ptr(), B, N, n, m, st),
-                       "iterativeLqr: backward pass")
-        # the 16-way line search packs 4 trajectories per wave: with a mask alone most waves would idle once most of the batch
-        # has converged, so the still-active trajectories go in as a compacted id list (checked against the mask in the kernel)
-        _lib.check(lib.zm_rollout_linesearch_list_f64(pmd, pcs, dx0.data_ptr(), l.data_ptr(), L.data_ptr(), xT.data_ptr(),
-                                                      uT.data_ptr(), alphas.data_ptr(), 16, ids.data_ptr(), int(ids.numel()), ap,
-                                                      xT2.data_ptr(), uT2.data_ptr(), Jn.data_ptr(), None, B, N, st),
-                   "iterativeLqr: forward pass")
-        # accept: converged = |J - J_new| <= tol, (traj, J) <- (traj_new, J_new) on the listed rows only             (:316-320)
-        _lib.check(lib.zm_ilqr_accept_f64(ids.data_ptr(), int(ids.numel()), J.data_ptr(), Jn.data_ptr(), xT.data_ptr(),
-                                          xT2.data_ptr(), uT.data_ptr(), uT2.data_ptr(), converged.data_ptr(),
-                                          active.data_ptr(), float(tol), B, N, n, m, st), "iterativeLqr: accept")
-        it += 1
+    if B:
+        # The whole loop -- initial rollout (:293-298), per iteration expansions, PD-conditioned Hessians, backward pass, 16-way
+        # line search, `converged = |J - J_new| <= tol` (:305-322) over the compacted list of still-active trajectories -- is ONE
+        # call into the C ABI: the host side of the iteration runs in C++ (zopt_amd/csrc/ilqr_solve.hip), no Python between the
+        # launches.  SYNC: host synchronisation (termination test + rebuild of the id list) every SYNC iterations; the results do
+        # not depend on it (an iteration over a converged trajectory touches nothing).
+        SYNC = max(1, int(os.environ.get("ZOPT_AMD_ILQR_SYNC", "4")))
+        nws = int(lib.zm_ilqr_solve_workspace_f64(pmd, B, N, 1 if ddp else 0))
+        if nws < 0:
+            raise ValueError("iterativeLqr: cannot size the workspace for this model")
+        ws = torch.empty(nws, dtype=dt, device=dev)
+        iwork = torch.empty(2 * B + 2, dtype=torch.int32, device=dev)
+        its = ctypes.c_int32(0)
+        rc = lib.zm_ilqr_solve_f64(pmd, pcs, dx0.data_ptr(), dug.data_ptr(), 1 if ddp else 0, int(maxIter), float(tol), SYNC,
+                                   ws.data_ptr(), nws, iwork.data_ptr(), xT.data_ptr(), uT.data_ptr(), L.data_ptr(), J.data_ptr(),
+                                   converged.data_ptr(), ctypes.addressof(its), B, N, st)
+        _lib.check(rc, "differentialDynamicProgramming" if ddp else "iterativeLqr")
+        if _TRACE is not None:
+            _TRACE.append(("iterations", int(its.value)))
     tmpl = uGuess
     fp32_in = (arr.is_torch(tmpl) and tmpl.dtype == torch.float32) or \
         (not arr.is_torch(tmpl) and np.asarray(tmpl).dtype == np.float32)
