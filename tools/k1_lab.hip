@@ -55,8 +55,10 @@ int main(int argc, char** argv) {
         {"product (nt loads, W=1)      ", lqr_backward_dma_f64<12, 4, 3, true, 0, 1>, 1},
         {"memory only                  ", lqr_backward_dma_f64<12, 4, 3, true, 32, 1>, 1},
         {"memory only, no store        ", lqr_backward_dma_f64<12, 4, 3, true, 32 | 128, 1>, 1},
-        {"memory only, nt stores       ", lqr_backward_dma_f64<12, 4, 3, true, 32 | 64, 1>, 1},
-        {"L2-resident inputs           ", lqr_backward_dma_f64<12, 4, 3, true, 1, 1>, 1},
+        {"memory only, L2-resident dest", lqr_backward_dma_f64<12, 4, 3, true, 32 | (1 << 19), 1>, 1},
+        {"stores only (no loads)       ", lqr_backward_dma_f64<12, 4, 3, true, 32 | (1 << 20), 1>, 1},
+        {"stores only, L2-resident dest", lqr_backward_dma_f64<12, 4, 3, true, 32 | (1 << 20) | (1 << 19), 1>, 1},
+        {"product, L2-resident dest    ", lqr_backward_dma_f64<12, 4, 3, true, (1 << 19), 1>, 1},
     };
     auto launch = [&](kern_t k, int blocks, int set, size_t dyn, int W = 1) {
         hipLaunchKernelGGL(k, dim3(blocks / W), dim3(64 * W), dyn, 0, A[set], B[set], Q[set], R[set], rot ? Lr[(lcount++) & 3] : L, T, (long)blocks);

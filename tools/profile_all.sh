@@ -15,7 +15,7 @@ run() {  # name, script args...
   [ -n "$f" ] && cp $f $OUT/${name}_kernel_stats.csv
   echo "== $name"; head -4 $OUT/${name}_kernel_stats.csv | cut -c1-160
 }
-run bench     $R/bench.py --no-cpu-baseline
+run bench     $R/bench.py --no-cpu-baseline --no-secondary
 run ilqr      $R/tools/bench_ilqr.py --reps 1
 run mpc       $R/tools/bench_mpc.py --eps 1e-2
 run tiled     $R/tools/bench_lqr_tiled.py --batch 2048 --reps 2

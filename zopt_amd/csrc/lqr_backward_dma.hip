@@ -150,12 +150,12 @@ __global__ __launch_bounds__(64 * W, 4) void lqr_backward_dma_f64(const double* 
     const int oYBr = YBO + ((cA ? c : 0) * M + g) * 8;      // Y_B[c][g]        A operand of Y_B (-L)
     const int oYBa = YBO + (g * M + (c & 3)) * 8;           // Y_B[4s+g][c & 3] (+ s*4*M*8): A operand of the 4x4x4 blocks (G4)
     const bool vL = cA;                                     // (g < M always: M == 4)
-    double* pL = L + (traj * T + (T - 1)) * nm + g * N + c;
+    double* pL = L + ((((X >> 19) & 1) ? (traj & 63) : traj) * T + (T - 1)) * nm + g * N + c;
 
     // prologue: fill the ring with steps T-1 .. T-D
 #pragma unroll
     for (int i = 0; i < D; ++i)
-        if (T - 1 - i >= 0) dma_issue<N, M, D, kAux>(a, lds + i * SLOT);
+        if (((X >> 20) & 1) == 0 && T - 1 - i >= 0) dma_issue<N, M, D, kAux>(a, lds + i * SLOT);
 
     double V[KS];
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, acc[5] = {0, 0, 0, 0, 0};
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64 * W, 4) void lqr_backward_dma_f64(const double* 
             const double rm = *(const double*)(slot + a.oRm);
             const double br = *(const double*)(slot + a.oBR);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // operands are in registers: the slot may be refilled
-            if (j - D >= 0) dma_issue<N, M, D, kAux>(a, slot);
+            if (((X >> 20) & 1) == 0 && j - D >= 0) dma_issue<N, M, D, kAux>(a, slot);
             ZM_STAMP(st1)
 #ifdef ZM_K1_LAB
             if constexpr ((X & 32) != 0) {   // memory only: the access pattern's own time (no MFMA, no solve)
