@@ -108,7 +108,11 @@ __device__ __forceinline__ typename TR::V4 load_tile(const typename TR::S* __res
     for (int r = 0; r < 4; ++r) {
         const int row = 16 * K + TR::row(g, r);
         if constexpr (EXACT) {
+#ifdef ZM_TILED_NT_LOADS
+            t[r] = __builtin_nontemporal_load(&X[row * ncols + col]);   // operands are streamed once (A/B build: -DZM_TILED_NT_LOADS)
+#else
             t[r] = X[row * ncols + col];
+#endif
         } else {
             const bool ok = row < nrows && col < ncols;
             const typename TR::S v = X[ok ? row * ncols + col : 0];
