@@ -52,13 +52,11 @@ int main(int argc, char** argv) {
 #define SM(k) ((k) << 13)
 #define SP(k) ((k) << 16)
     std::vector<Variant> vs = {
-        {"product (nt loads, W=1)      ", lqr_backward_dma_f64<12, 4, 3, true, 0, 1>, 1},
-        {"memory only                  ", lqr_backward_dma_f64<12, 4, 3, true, 32, 1>, 1},
-        {"memory only, no store        ", lqr_backward_dma_f64<12, 4, 3, true, 32 | 128, 1>, 1},
-        {"memory only, L2-resident dest", lqr_backward_dma_f64<12, 4, 3, true, 32 | (1 << 19), 1>, 1},
-        {"stores only (no loads)       ", lqr_backward_dma_f64<12, 4, 3, true, 32 | (1 << 20), 1>, 1},
-        {"stores only, L2-resident dest", lqr_backward_dma_f64<12, 4, 3, true, 32 | (1 << 20) | (1 << 19), 1>, 1},
-        {"product, L2-resident dest    ", lqr_backward_dma_f64<12, 4, 3, true, (1 << 19), 1>, 1},
+        {"product (nt loads, D=3, 4 w/SIMD)", lqr_backward_dma_f64<12, 4, 3, true, 0, 1, 4>, 1},
+        {"D=2, 4 waves/SIMD             ", lqr_backward_dma_f64<12, 4, 2, true, 0, 1, 4>, 1},
+        {"D=2, 5 waves/SIMD (<= 96 VGPR)", lqr_backward_dma_f64<12, 4, 2, true, 0, 1, 5>, 1},
+        {"D=2, 5 w/SIMD, L2-resident    ", lqr_backward_dma_f64<12, 4, 2, true, 1, 1, 5>, 1},
+        {"D=3, 4 w/SIMD, L2-resident    ", lqr_backward_dma_f64<12, 4, 3, true, 1, 1, 4>, 1},
     };
     auto launch = [&](kern_t k, int blocks, int set, size_t dyn, int W = 1) {
         hipLaunchKernelGGL(k, dim3(blocks / W), dim3(64 * W), dyn, 0, A[set], B[set], Q[set], R[set], rot ? Lr[(lcount++) & 3] : L, T, (long)blocks);
@@ -67,7 +65,7 @@ int main(int argc, char** argv) {
         std::vector<double> ref(nB), got(nB);
         launch(vs[0].k, batch, 0, 0, 1);
         CHK(hipMemcpy(ref.data(), L, nB * 8, hipMemcpyDeviceToHost));
-        for (size_t v : {(size_t)0}) {
+        for (size_t v : {(size_t)1, (size_t)2}) {
             if (rot) break;
             CHK(hipMemset(L, 0xff, nB * 8));
             launch(vs[v].k, batch, 0, 0, vs[v].W);

@@ -1,0 +1,17 @@
+#!/bin/bash
+# PMC counters (separate passes) for any command; per-kernel means via tools/pmc_summary.py.
+# usage (GPU box, repo root): bash tools/pmc_kernel.sh <outdir-under-gpurun_out> <kernel substring> -- <python script and args>
+set -u
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$1; KERN=$2; shift 3
+mkdir -p $OUT
+cd /tmp
+i=0
+for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE" \
+         "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pass$i -- python3 "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed"
+done
+python3 $R/tools/pmc_summary.py $OUT $KERN > $OUT/summary.txt
+cat $OUT/summary.txt

@@ -84,8 +84,8 @@ __device__ unsigned long long zm_k1_stamps[8];
 
 // W: waves per workgroup.  Wave w of block b owns trajectory b * W + w; the waves never synchronise or share data -- a larger
 // workgroup only makes the co-resident waves of a CU work on ADJACENT trajectories (fewer distinct pages per CU).
-template <int N, int M, int D, bool G4, int X = 0, int W = 1>
-__global__ __launch_bounds__(64 * W, 4) void lqr_backward_dma_f64(const double* __restrict__ A,
+template <int N, int M, int D, bool G4, int X = 0, int W = 1, int WPS = 4>
+__global__ __launch_bounds__(64 * W, WPS) void lqr_backward_dma_f64(const double* __restrict__ A,
                                                                   const double* __restrict__ B,
                                                                   const double* __restrict__ Q,
                                                                   const double* __restrict__ R, double* __restrict__ L,
