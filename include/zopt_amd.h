@@ -36,8 +36,12 @@ int zm_version(void);
 /* Thread-local description of the last error returned on this thread ("" if none). */
 const char* zm_last_error(void);
 
-/* 1 if (n, m) is covered by the compiled LQR sweep kernels for the given element size (8 = fp64: tile-16 MFMA kernels
- * for n <= 12, m <= 4, LDS coverage kernel up to n <= 64, m <= 16; 4 = fp32: zm_lqr_backward_f32), else 0. */
+/* 1 if (n, m) is covered by the compiled LQR sweep kernels for the given element size, else 0.
+ *   8 = fp64: tile-16 MFMA kernels for n <= 12, m <= 4 (the LDS-DMA fast path at n in {8, 12}, m = 4: ~1.5e9 steps/s at (12, 4));
+ *             register-tile fp64 MFMA kernel for n <= 48, m <= 16 (47 M steps/s at (48, 16)); for 48 < n <= 64 an LDS-resident
+ *             COVERAGE kernel that is correct but untuned -- 1.4 M steps/s at n = 64, a 30x cliff against n = 48: use fp32
+ *             (zm_lqr_backward_f32: 62 M steps/s at (64, 16)) when that precision is acceptable;
+ *   4 = fp32: zm_lqr_backward_f32, n <= 64, m <= 16 (n <= 12, m <= 4 are computed in fp64 and rounded once). */
 int zm_lqr_backward_supported(int n, int m, int elem_size);
 
 /* Batched discrete finite-horizon LQR backward Riccati recursion (Joseph-form value update).
