@@ -119,11 +119,7 @@ __device__ __forceinline__ void ilqr_load_step(IlqrStepRegs<KS>& d, IlqrAddr<KS>
 //                       MODE 1: [96,112) V^T d (column-indexed); [112,116) l
 constexpr int ILQR_LDS_DOUBLES = 116;
 
-__device__ __forceinline__ void ilqr_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+__device__ __forceinline__ void ilqr_lds_sync() { wave_lds_sync(); }
 
 template <int KS, int MODE, bool PREFETCH>
 __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], IlqrStepRegs<KS>& d, IlqrAddr<KS>& a,

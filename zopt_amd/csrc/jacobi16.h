@@ -3,6 +3,7 @@
 // Used by psd.hip (K5) and by the DDP backward step (K4), where the projection sits inside the sequential sweep
 // (zopt/ilqrUtils.py:217-219, 237-251).
 #pragma once
+#include "zm_common.h"
 #include <hip/hip_runtime.h>
 
 namespace zm {
@@ -10,11 +11,7 @@ namespace zm {
 constexpr int PK = 16;   // max matrix size
 constexpr int PLD = 17;  // padded leading dimension in LDS
 
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+// (wave_lds_sync: zm_common.h)
 
 __device__ __forceinline__ double jac_rsqrt(const double x) {   // 1/sqrt(x), x > 0: hardware estimate + 2 Newton steps
     double y = __builtin_amdgcn_rsq(x);

@@ -84,6 +84,19 @@ __device__ unsigned long long zm_k1_stamps[8];
 
 // W: waves per workgroup.  Wave w of block b owns trajectory b * W + w; the waves never synchronise or share data -- a larger
 // workgroup only makes the co-resident waves of a CU work on ADJACENT trajectories (fewer distinct pages per CU).
+// LDS write -> read by another lane of the wave: zm::wave_lds_sync (zm_common.h: compiler-level barrier); HEAVY = the round-1 form
+// (fences + wave barrier), kept for the lab's A/B (X bit 21).
+template <bool HEAVY>
+__device__ __forceinline__ void k1_lds_sync() {
+    if constexpr (HEAVY) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        wave_lds_sync();
+    }
+}
+
 template <int N, int M, int D, bool G4, int X = 0, int W = 1, int WPS = 4>
 __global__ __launch_bounds__(64 * W, WPS) void lqr_backward_dma_f64(const double* __restrict__ A,
                                                                   const double* __restrict__ B,
@@ -216,9 +229,7 @@ __global__ __launch_bounds__(64 * W, WPS) void lqr_backward_dma_f64(const double
                 // (64 cycles each) the 4 x 16 result is computed as four 4x4 blocks by v_mfma_f64_4x4x4_4b (16 cycles each):
                 // block q = c >> 2 takes B_q[k][j] = F[4s+k][4q+j] -- exactly the registers f4[s] already hold -- and
                 // A_q[u][k] = Y_B[4s+k][u], read back from LDS as Y_B[4s+g][c & 3]; lane (g, c) receives S[g][c].
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                k1_lds_sync<((X >> 21) & 1) != 0>();
                 double ya[KS];
 #pragma unroll
                 for (int s = 0; s < KS; ++s) ya[s] = *(const double*)(lds + oYBa + s * (4 * M * 8));
@@ -236,9 +247,7 @@ __global__ __launch_bounds__(64 * W, WPS) void lqr_backward_dma_f64(const double
             ZM_STAMP(st2)
             // m x m solve: 4 x 16 tile through LDS, every lane reads Suu (broadcast) and its own RHS column
             exch[g * 16 + c] = srow;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            k1_lds_sync<((X >> 21) & 1) != 0>();
             double S[4][4], b[4], x[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(64 * W, WPS) void lqr_backward_dma_f64(const double
                 // rare: growth check failed somewhere in the wave -> partial pivoting, IEEE division
                 lu_solve4(S, b, x);
             }
-            __builtin_amdgcn_wave_barrier();
+            if constexpr (((X >> 21) & 1) != 0) __builtin_amdgcn_wave_barrier();
             const double x01 = (g & 1) ? x[1] : x[0];
             const double x23 = (g & 1) ? x[3] : x[2];
             const double lv = (g & 2) ? x23 : x01;  // L_k[g][c]

@@ -11,11 +11,7 @@ namespace zm {
 typedef float tf4 __attribute__((ext_vector_type(4)));
 typedef double td4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void t_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+__device__ __forceinline__ void t_lds_sync() { wave_lds_sync(); }
 
 // v_mfma_f32_16x16x4_f32: accumulator register r of lane (g, c) holds row 4g + r.
 struct TileF32 {

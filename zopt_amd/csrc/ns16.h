@@ -18,17 +18,14 @@
 // Rows / columns outside the live index set are zero and stay zero (live[r] marks the diagonal entries of the live set).
 #pragma once
 #include "tile16_f64.h"
+#include "zm_common.h"
 
 namespace zm {
 
 constexpr int NS_LD = 17;                 // padded leading dimension of the transpose buffers
 constexpr int NS_LDS_DOUBLES = 2 * 16 * NS_LD;
 
-__device__ __forceinline__ void ns_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+__device__ __forceinline__ void ns_sync() { wave_lds_sync(); }
 
 // 32-bit halves of a double through one DPP move (VALU speed; __shfl_xor would be two ds_bpermute round trips per level)
 template <int CTRL>
