@@ -17,6 +17,70 @@ __device__ __forceinline__ void t_lds_sync() { wave_lds_sync(); }
 struct TileF32 {
     using S = float;
     using V4 = tf4;
+    static constexpr bool FUSED_DPP = true;   // the solve's broadcasts ride on the FMA (v_fmac_f32_dpp ... row_newbcast)
+    // One batch of the elimination at pivot KK, rows r0 .. r0+CNT-1 (lane (g, c) holds column c of Suu in u[], one column of Sux in
+    // x[]): m_q = u_q * inv (the multipliers, meaningful in lane c == KK of every 16-lane row), then
+    //     x_q += bcast_KK(m_q) * nxk,   u_q += bcast_KK(m_q) * nuk         (nxk = -x[KK], nuk = -u[KK])
+    // with the broadcast as the DPP operand of the FMA itself: 3 instructions per row instead of 5 (multiplier, v_readlane, two
+    // FMAs) and no scalar registers.  ONE asm statement: the CNT multiplies come first, so every multiplier is at least two
+    // instructions old when a DPP operand reads it (the wait states hipcc does not insert inside asm).
+    template <int KK, int CNT>
+    static __device__ __forceinline__ void elim_batch(const float inv, const float nxk, const float nuk, float (&m)[4], float& x0,
+                                                      float& x1, float& x2, float& x3, float& u0, float& u1, float& u2, float& u3) {
+        if constexpr (CNT == 4)
+            asm("v_mul_f32 %0, %8, %12\n\tv_mul_f32 %1, %9, %12\n\tv_mul_f32 %2, %10, %12\n\tv_mul_f32 %3, %11, %12\n\t"
+                "v_fmac_f32_dpp %4, %0, %13 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+                "v_fmac_f32_dpp %8, %0, %14 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+                "v_fmac_f32_dpp %5, %1, %13 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+                "v_fmac_f32_dpp %9, %1, %14 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+                "v_fmac_f32_dpp %6, %2, %13 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+                "v_fmac_f32_dpp %10, %2, %14 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+                "v_fmac_f32_dpp %7, %3, %13 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+                "v_fmac_f32_dpp %11, %3, %14 row_newbcast:%15 row_mask:0xf bank_mask:0xf"
+                : "=&v"(m[0]), "=&v"(m[1]), "=&v"(m[2]), "=&v"(m[3]), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(u0), "+v"(u1),
+                  "+v"(u2), "+v"(u3)
+                : "v"(inv), "v"(nxk), "v"(nuk), "i"(KK));
+        else if constexpr (CNT == 3)
+            asm("v_mul_f32 %0, %6, %9\n\tv_mul_f32 %1, %7, %9\n\tv_mul_f32 %2, %8, %9\n\t"
+                "v_fmac_f32_dpp %3, %0, %10 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+                "v_fmac_f32_dpp %6, %0, %11 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+                "v_fmac_f32_dpp %4, %1, %10 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+                "v_fmac_f32_dpp %7, %1, %11 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+                "v_fmac_f32_dpp %5, %2, %10 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+                "v_fmac_f32_dpp %8, %2, %11 row_newbcast:%12 row_mask:0xf bank_mask:0xf"
+                : "=&v"(m[0]), "=&v"(m[1]), "=&v"(m[2]), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(u0), "+v"(u1), "+v"(u2)
+                : "v"(inv), "v"(nxk), "v"(nuk), "i"(KK));
+        else if constexpr (CNT == 2)
+            asm("v_mul_f32 %0, %4, %6\n\tv_mul_f32 %1, %5, %6\n\ts_nop 0\n\t"
+                "v_fmac_f32_dpp %2, %0, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                "v_fmac_f32_dpp %4, %0, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                "v_fmac_f32_dpp %3, %1, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                "v_fmac_f32_dpp %5, %1, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+                : "=&v"(m[0]), "=&v"(m[1]), "+v"(x0), "+v"(x1), "+v"(u0), "+v"(u1)
+                : "v"(inv), "v"(nxk), "v"(nuk), "i"(KK));
+        else
+            asm("v_mul_f32 %0, %2, %3\n\ts_nop 1\n\t"
+                "v_fmac_f32_dpp %1, %0, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+                "v_fmac_f32_dpp %2, %0, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+                : "=&v"(m[0]), "+v"(x0), "+v"(u0)
+                : "v"(inv), "v"(nxk), "v"(nuk), "i"(KK));
+    }
+    // acc += bcast_L(v) * c  (substitution: v = -u[kk] of the row, lane L holds column L's entry)
+    template <int L>
+    static __device__ __forceinline__ void fma_bc(float& acc, const float v, const float c) {
+        asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(c), "i"(L));
+    }
+    // bcast_L(v) * c
+    template <int L>
+    static __device__ __forceinline__ float mul_bc(const float v, const float c) {
+        float r;
+        asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "v"(c), "i"(L));
+        return r;
+    }
+    static __device__ __forceinline__ float dpp_src(float v) {   // two wait states between a VALU write and a DPP read of v
+        asm("s_nop 1" : "+v"(v));
+        return v;
+    }
     static constexpr int TLD = 20;   // row stride of the LDS buffers (floats): 80 B rows keep the b128 accesses 16 B-aligned
     static __device__ __forceinline__ V4 zero() { return V4{0.f, 0.f, 0.f, 0.f}; }
     static __device__ __forceinline__ int row(const int g, const int r) { return 4 * g + r; }
@@ -50,6 +114,7 @@ struct TileF32 {
 struct TileF64 {
     using S = double;
     using V4 = td4;
+    static constexpr bool FUSED_DPP = false;
     static constexpr int TLD = 18;   // 144 B rows
     static __device__ __forceinline__ V4 zero() { return V4{0.0, 0.0, 0.0, 0.0}; }
     static __device__ __forceinline__ int row(const int g, const int r) { return 4 * r + g; }
@@ -118,6 +183,80 @@ __device__ __forceinline__ typename TR::V4 load_tile(const typename TR::S* __res
     return t;
 }
 
+// Elimination / substitution of the 16 x 16 solve with the broadcasts fused into the FMAs (TR::FUSED_DPP): compile-time recursion over
+// the pivot, because the DPP control (row_newbcast:KK) is an immediate.  x: the lane's column of Sux; u: its column of Suu;
+// inv[kk]: 1 / pivot kk (meaningful in lane c == kk of every 16-lane row).
+template <class TR, int KK>
+__device__ __forceinline__ void solve_elim(typename TR::S (&x)[16], typename TR::S (&u)[16], typename TR::S (&inv)[16], bool& okm,
+                                           unsigned long long& bad) {
+    using S = typename TR::S;
+    if constexpr (KK < 16) {
+        inv[KK] = TR::rcp(u[KK]);
+        const S nxk = -x[KK], nuk = -u[KK];
+        // growth check of the unpivoted elimination: the squares of the column's multipliers must sum to <= 16, which implies
+        // every |multiplier| <= 4 (the bound of the register-level fast path); one FMA per row instead of a compare and a
+        // mask update, and a NaN or infinite multiplier fails it (NaN compares false)
+        S sq = S(0);
+        constexpr int R0 = KK + 1;
+#define ZM_ELIM_BATCH(B)                                                                                                        \
+        if constexpr (R0 + 4 * (B) < 16) {                                                                                      \
+            constexpr int r0 = R0 + 4 * (B), cnt = (16 - r0) < 4 ? (16 - r0) : 4;                                               \
+            S m[4] = {S(0), S(0), S(0), S(0)};                                                                                  \
+            constexpr int i1 = r0 + 1 < 16 ? r0 + 1 : 15, i2 = r0 + 2 < 16 ? r0 + 2 : 15, i3 = r0 + 3 < 16 ? r0 + 3 : 15;       \
+            TR::template elim_batch<KK, cnt>(inv[KK], nxk, nuk, m, x[r0], x[i1], x[i2], x[i3], u[r0], u[i1], u[i2], u[i3]);     \
+            _Pragma("unroll") for (int q = 0; q < cnt; ++q) sq = TR::fma(m[q], m[q], sq);   /* NaN / inf propagate */               \
+        }
+        ZM_ELIM_BATCH(0)
+        ZM_ELIM_BATCH(1)
+        ZM_ELIM_BATCH(2)
+        ZM_ELIM_BATCH(3)
+#undef ZM_ELIM_BATCH
+        bad |= __ballot(!(sq <= S(16))) & (0x0001000100010001ull << KK);   // only lane c == KK of each row holds the column's multipliers
+        (void)okm;
+        solve_elim<TR, KK + 1>(x, u, inv, okm, bad);
+    }
+}
+
+template <class TR, int KK, int R>
+__device__ __forceinline__ void subst_terms(typename TR::S& a0, typename TR::S& a1, const typename TR::S nuk, const typename TR::S (&x)[16]) {
+    if constexpr (R < 16) {
+        if constexpr ((R - KK) & 1)
+            TR::template fma_bc<R>(a0, nuk, x[R]);     // a0 += bcast_R(-U[KK][R]) * x[R]
+        else
+            TR::template fma_bc<R>(a1, nuk, x[R]);
+        subst_terms<TR, KK, R + 1>(a0, a1, nuk, x);
+    }
+}
+
+template <class TR, int KK>
+__device__ __forceinline__ void solve_subst(typename TR::S (&x)[16], const typename TR::S (&u)[16], const typename TR::S (&inv)[16]) {
+    using S = typename TR::S;
+    if constexpr (KK >= 0) {
+        S a0 = x[KK], a1 = S(0);
+        const S nuk = TR::dpp_src(-u[KK]);             // lane R of a row holds -U[KK][R]
+        subst_terms<TR, KK, KK + 1>(a0, a1, nuk, x);
+        x[KK] = TR::template mul_bc<KK>(TR::dpp_src(inv[KK]), a0 + a1);   // (a0 + a1) / pivot
+        solve_subst<TR, KK - 1>(x, u, inv);
+    }
+}
+
+// Diagnostic build (-DZM_TILED_LAB, tools/k1t_lab.hip): s_memtime stamps at the phase boundaries of a step, summed per wave into
+// zm_tiled_stamps.  The stamps' waits forbid overlaps the product has: read SHARES, not lengths.
+#ifdef ZM_TILED_LAB
+__device__ unsigned long long zm_tiled_stamps[12];
+#define ZT_STAMP(i)                                                                                   \
+    {                                                                                                 \
+        unsigned long long t_;                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        zt_acc[i] += t_ - zt_last;                                                                    \
+        zt_last = t_;                                                                                 \
+    }
+#else
+#define ZT_STAMP(i)
+#endif
+
 template <class TR, int NT, bool EXACT>
 __global__ __launch_bounds__(64) void lqr_backward_tiled(const typename TR::S* __restrict__ A, const typename TR::S* __restrict__ B,
                                                          const typename TR::S* __restrict__ Q, const typename TR::S* __restrict__ R,
@@ -160,12 +299,17 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled(const typename TR::S* _
     }
     Rn = load_tile<TR, EXACT>(Rb + (long)(T - 1) * mm, m, m, 0, 0, g, c, S(1));
 
+#ifdef ZM_TILED_LAB
+    unsigned long long zt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, zt_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(zt_last)::"memory");
+#endif
     for (int k = T - 1; k >= 0; --k) {
 #pragma unroll
         for (int K = 0; K < NT; ++K)
 #pragma unroll
             for (int J = 0; J <= NT; ++J) F[K][J] = Fn[K][J];
         Rt = Rn;
+        ZT_STAMP(0)   // loop head: waits for the operands of this step (issued during the previous step)
         // Y_B = V^T B
 #pragma unroll
         for (int I = 0; I < NT; ++I) {
@@ -189,6 +333,7 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled(const typename TR::S* _
             TR::tile_to_lds(Tb[NT + K], Y[K][NT], g, c);
         }
         TR::tile_to_lds(Tb[2 * NT], Rt, g, c);
+        ZT_STAMP(1)   // Y_B, S (144 MFMAs at NT = 4) and the LDS writes of S and the transposed tiles
         t_lds_sync();
         // column j of Sux and column c of Suu into registers
         S x[16], u[16];
@@ -202,11 +347,14 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled(const typename TR::S* _
         // the Y_A sequence (row-tile I outermost) and closes the scheduling region, so the order written here is the order
         // executed: one MFMA per elimination / substitution unit.  When row-tile I is complete the V tiles it read (column I)
         // are dead and take Q_k[*][I], the accumulator init of V'.
+        ZT_STAMP(2)   // solve operands from LDS
         int yq = 0;   // running MFMA number: a constant at every call once the loops below are unrolled
         auto ya = [&]() {
             const int t = yq++;
             if (t < 4 * NT * NT * NT) {
-                const int s_ = t & 3, K_ = (t >> 2) % NT, J_ = ((t >> 2) / NT) % NT, I_ = (t >> 2) / (NT * NT);
+                // column tile J fastest: consecutive MFMAs accumulate into NT different tiles (a chain of 16 MFMAs into one tile runs
+                // at the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32, not at its 32-cycle issue rate)
+                const int J_ = t % NT, s_ = (t / NT) & 3, K_ = (t / (4 * NT)) % NT, I_ = t / (4 * NT * NT);
                 const f4 a_ = (K_ == 0 && s_ == 0) ? TR::zero() : Y[I_][J_];
                 Y[I_][J_] = TR::mfma(V[K_][I_][s_], F[K_][J_][s_], a_);
                 if ((t + 1) % (4 * NT * NT) == 0) {
@@ -214,7 +362,6 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled(const typename TR::S* _
                     for (int K = 0; K < NT; ++K) V[K][I_] = load_tile<TR, EXACT>(Qb + k * nn, n, n, K, I_, g, c);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
         };
         __builtin_amdgcn_sched_barrier(0);
 
@@ -224,39 +371,95 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled(const typename TR::S* _
         //      result differs from jnp.linalg.solve's pivoted LU by rounding only.  Otherwise: pivoted LU in LDS (below).
         unsigned long long bad = 0ull;
         S pinv[16];
+      if constexpr (TR::FUSED_DPP) {
+        // fp32 MFMA and fp32 VALU share the vector ALU (the fp32 "matrix peak" IS the vector rate): the solve's VALU work does not
+        // hide under the Y_A MFMAs, it ADDS to them (stamps: 16.1 k cycles for this phase = 8.2 k of MFMA + the vector
+        // instructions).  What counts is therefore the NUMBER of vector instructions: the broadcasts ride on the FMAs
+        // (TR::elim_batch / fma_bc: v_fmac_f32_dpp row_newbcast), three instructions per eliminated row instead of five, one per
+        // substitution term instead of two, no wave-uniform copies in scalar registers.
+        bool okm = true;
+        solve_elim<TR, 0>(x, u, pinv, okm, bad);
+        bad |= __ballot(!(TR::abs(pinv[15]) < TR::huge())) & (0x0001000100010001ull << 15);
+        solve_subst<TR, 15>(x, u, pinv);
+#pragma unroll
+        for (int t = 0; t < 4 * NT * NT * NT; ++t) ya();
+      } else {
+        // Every stage below is a run of mutually INDEPENDENT instructions (all multipliers of a column, then all their wave-uniform
+        // copies, then all row updates), with one Y_A MFMA after every ~4 of them: issued in the order written (ya() closes the
+        // scheduling region), a unit-by-unit order (multiplier -> readlane -> its two FMAs) stalls on each dependency and the
+        // phase ran at twice the MFMA time (stamps: 16.1 k cycles against 8.2 k of MFMA issue; tools/k1t_lab.hip).
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const S inv = TR::rcp(u[kk]);
             pinv[kk] = TR::readlane(inv, kk);
             ya();
+            bool okm = true;
+            // rows in batches of four: 4 multipliers, their 4 wave-uniform copies, 8 updates -- independent instructions inside a
+            // stage, few enough uniform values alive at a time for the scalar register file
 #pragma unroll
-            for (int r = kk + 1; r < 16; ++r) {
-                const S mv = u[r] * inv;
-                bad |= __ballot(!(TR::abs(mv) <= S(4))) & (0x0001000100010001ull << kk);
-                const S ms = TR::readlane(mv, kk);
-                x[r] = TR::fma(-ms, x[kk], x[r]);
-                u[r] = TR::fma(-ms, u[kk], u[r]);
+            for (int bq = 0; bq < 4; ++bq) {      // (constant trip counts: the unroller must see them before kk is a constant)
+                const int r0 = kk + 1 + 4 * bq;
+                if (r0 >= 16) continue;
+                S mv[4], ms[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (r0 + q < 16) {
+                        mv[q] = u[r0 + q] * inv;
+                        okm &= (TR::abs(mv[q]) <= S(4));   // NaN compares false: a NaN multiplier fails the check
+                    }
                 ya();
-                if (((kk * 15 - kk * (kk - 1) / 2 + (r - kk - 1)) & 1) != 0) ya();   // an elimination unit is ~1.5 MFMAs long,
-                                                                                     // a substitution unit ~0.5
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (r0 + q < 16) ms[q] = TR::readlane(mv[q], kk);
+                ya();
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (r0 + q < 16) {
+                        x[r0 + q] = TR::fma(-ms[q], x[kk], x[r0 + q]);
+                        u[r0 + q] = TR::fma(-ms[q], u[kk], u[r0 + q]);
+                        if (q == 1) ya();
+                    }
+                ya();
             }
+            bad |= __ballot(!okm) & (0x0001000100010001ull << kk);   // only lane c == kk of each group holds the column's multipliers
+            ya();
         }
         bad |= __ballot(!(TR::abs(pinv[15]) < TR::huge()));
 #pragma unroll
         for (int kk = 15; kk >= 0; --kk) {
-            S acc = x[kk];
+            S a0 = x[kk], a1 = S(0);                      // two partial chains over the row
 #pragma unroll
-            for (int r = kk + 1; r < 16; ++r) {
-                acc = TR::fma(-TR::readlane(u[kk], r), x[r], acc);
-                if (((kk * 15 - kk * (kk - 1) / 2 + (r - kk - 1)) & 1) == 0) ya();
+            for (int bq = 0; bq < 4; ++bq) {
+                const int r0 = kk + 1 + 4 * bq;
+                if (r0 >= 16) continue;
+                S ur[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (r0 + q < 16) ur[q] = TR::readlane(u[kk], r0 + q);
+                ya();
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (r0 + q < 16) {
+                        if (q & 1)
+                            a1 = TR::fma(-ur[q], x[r0 + q], a1);
+                        else
+                            a0 = TR::fma(-ur[q], x[r0 + q], a0);
+                    }
+                ya();
             }
-            x[kk] = acc * pinv[kk];
+            x[kk] = (a0 + a1) * pinv[kk];
+            ya();
         }
-        static_assert(4 * NT * NT * NT <= 256, "the 256 ya() calls above must cover the Y_A sequence");
+      }
+        // (readlane path) ya() is called 260 times above (16 + 36 x 3 + 32 + 16 in the elimination, 36 x 2 + 16 in the substitution): the whole Y_A
+        // sequence (256 MFMAs at NT = 4) is issued.  The count must stay a compile-time fact -- a loop that the compiler does not
+        // unroll turns the tile indices inside ya() into run-time values and the register-resident tiles into scratch arrays.
+        static_assert(4 * NT * NT * NT <= 256, "the Y_A sequence is at most 256 MFMAs");
         // The pivoted path below overwrites x, so the optimiser would sink the whole substitution past the branch -- away from
         // the MFMAs it is meant to hide under.  Pin the values here.
 #pragma unroll
         for (int u_ = 0; u_ < 16; ++u_) TR::pin(x[u_]);
+        ZT_STAMP(3)   // solve interleaved with Y_A (256 MFMAs)
         if (bad != 0ull) {   // wave-uniform, rare: LU with partial pivoting on the copy still in LDS (getrf / getrs order)
 #define S_(r_, j_) Sc[(j_) * TLD + (r_)]
 #pragma unroll 1
@@ -326,6 +529,7 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled(const typename TR::S* _
         for (int J = 0; J < NT; ++J)
 #pragma unroll
             for (int r = 0; r < 4; ++r) NL[J][r] = Sc[(16 * J + c) * TLD + TR::row(g, r)];
+        ZT_STAMP(4)   // L store, -L through LDS back as tiles
         {  // operands of step k-1, fetched under the ~15k cycles of MFMAs that follow (the last iteration re-reads step 0:
            // no branch around the loads); issued only now so that they do not hold 84 registers during the solve
             const int kn = k > 0 ? k - 1 : 0;
@@ -338,6 +542,7 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled(const typename TR::S* _
             Rn = load_tile<TR, EXACT>(Rb + kn * mm, m, m, 0, 0, g, c, S(1));
         }
         __builtin_amdgcn_sched_barrier(0);   // all 84 loads in flight before the MFMA stream starts
+        ZT_STAMP(5)   // issue of the next step's operand loads
         // -RL = R (-L)
         {
             const f4 RT = TR::tile_from_lds_T(Tb[2 * NT], g, c);
@@ -366,7 +571,14 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled(const typename TR::S* _
                 V[I][J] = acc;
             }
         t_lds_sync();  // Sc / Tb are rewritten by the next step
+        ZT_STAMP(6)   // -RL, Acl, W, V' (464 MFMAs)
     }
+#ifdef ZM_TILED_LAB
+    if (lane == 0) {
+        for (int q = 0; q < 7; ++q) atomicAdd(&zm_tiled_stamps[q], zt_acc[q]);
+        atomicAdd(&zm_tiled_stamps[7], 1ull);
+    }
+#endif
 }
 
 
