@@ -1,0 +1,44 @@
+"""The solvers' line search has two forms (zopt_amd/csrc/ilqr_solve.hip): the two-pass one (winner re-rolled) and, once at most
+ZOPT_AMD_ILQR_TAIL trajectories are left, the all-store one (every step size's rollout kept in scratch, the accept step copies the
+winner).  Both run the same arithmetic, so a solve must come out BIT-identical whichever threshold is set -- never, always, or
+switching in the middle of the solve.  The threshold is read once per process: one child process per value."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from zopt_amd import ilqrUtils, models
+ddp = sys.argv[2] == "ddp"
+rng = np.random.default_rng(11)
+B, N = 96, 30
+x0 = np.zeros((B, 12)); x0[:, 9:12] = rng.uniform(-10, 10, (B, 3))
+ug = np.tile(models.QuadcopterEuler.uTrim, (B, N, 1))
+cost = models.QuadraticCost(np.eye(12), (0.2 if ddp else 1.0) * np.eye(4), 10 * np.eye(12))
+solve = ilqrUtils.differentialDynamicProgramming if ddp else ilqrUtils.iterativeLqr
+traj, L, J, conv = solve(models.QuadcopterEuler(0.1), cost, cost, x0, ug)
+np.savez(sys.argv[1], x=np.asarray(traj.xTraj), u=np.asarray(traj.uTraj), L=np.asarray(L), J=np.asarray(J), c=np.asarray(conv))
+print("CHILD-OK", int(np.sum(conv)))
+""" % ROOT
+
+
+@pytest.mark.parametrize("solver", ["ilqr", "ddp"])
+def test_solve_is_bit_identical_for_every_tail_threshold(solver, tmp_path):
+    res = {}
+    for thr in ("0", "1000000", "40"):      # never / from the first iteration / switches when 40 of the 96 are left
+        out = tmp_path / f"{solver}_{thr}.npz"
+        p = subprocess.run([sys.executable, "-c", CHILD, str(out), solver], env=dict(os.environ, ZOPT_AMD_ILQR_TAIL=thr),
+                           capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert p.returncode == 0 and "CHILD-OK" in p.stdout, (p.stdout[-300:], p.stderr[-1500:])
+        res[thr] = dict(np.load(out))
+    assert res["0"]["c"].sum() > 48                      # the problem set mostly converges (a real solve, not a no-op)
+    for thr in ("1000000", "40"):
+        for k in ("x", "u", "L", "J", "c"):
+            assert np.array_equal(res["0"][k], res[thr][k], equal_nan=True), (solver, thr, k)

@@ -10,6 +10,7 @@
 // The kernels are the ones behind the array-level entry points (linearize.hip, ilqr_backward.hip, rollout*.hip, psd.hip);
 // nothing is allocated here: the caller provides the workspace (zm_ilqr_solve_workspace_f64 tells how much).
 #include <cstdint>
+#include <cstdlib>
 
 #include "zm_common.h"
 
@@ -55,8 +56,31 @@ __global__ void fill_f64_kernel(double* __restrict__ p, const long n, const doub
 }
 
 struct IlqrWs {   // carve of the caller's workspace (doubles)
-    long l, xT2, uT2, Jn, f_x, f_u, c_x, c_u, v_x, c_xx, c_ux, c_uu, v_xx, alphas, f_xx, f_ux, f_uu, total;
+    long l, xT2, uT2, Jn, f_x, f_u, c_x, c_u, v_x, c_xx, c_ux, c_uu, v_xx, alphas, f_xx, f_ux, f_uu, idx, scratch, tail_slots, total;
 };
+
+// Once at most this many trajectories are left, the line search runs in all-store mode (rollout_fast.hip): its 16 rollouts per
+// trajectory go to scratch rows and the accept step copies the winner, instead of re-rolling the winner in a second pass of T more
+// dependent steps.  With few trajectories a launch lasts as long as one wave's chain, so this halves it; with many, the 16x stores
+// (207 KB per trajectory at n=12, m=4, T=100) would cost more HBM time than the second pass costs ALU time.
+// ZOPT_AMD_ILQR_TAIL=<n> overrides the threshold (0: never).
+constexpr long ILQR_TAIL_DEFAULT = 2048;
+static long ilqr_tail_slots(long batch) {
+    static const long thr = [] {
+        const char* e = getenv("ZOPT_AMD_ILQR_TAIL");
+        return e ? atol(e) : ILQR_TAIL_DEFAULT;
+    }();
+    return thr < 0 ? 0 : (thr < batch ? thr : batch);
+}
+
+bool rollout_all_store_supported(const zm_model_t* model, const zm_quadcost_t* cost, int T);
+int rollout_linesearch_all_store(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0, const double* l, const double* L,
+                                 const double* xPrev, const double* uPrev, const double* alphas, const int32_t* list, int64_t count,
+                                 const int32_t* active, double* scratch, double* J, int32_t* alpha_idx, int64_t batch, int T,
+                                 void* stream);
+int ilqr_accept(const int32_t* list, int64_t count, double* J, const double* Jn, double* xTraj, const double* xTrajNew, double* uTraj,
+                const double* uTrajNew, int32_t* converged, int32_t* active, double tol, int64_t batch, int T, int n, int m,
+                void* stream, const double* scratch, const int32_t* idx);
 
 static IlqrWs carve(long b, long T, long n, long m, int ddp, int need_ux, int npairs) {
     IlqrWs w;
@@ -84,6 +108,9 @@ static IlqrWs carve(long b, long T, long n, long m, int ddp, int need_ux, int np
     w.f_xx = ddp ? take(npairs > 0 ? b * T * npairs * n : b * T * n * n * n) : 0;
     w.f_ux = (ddp && need_ux && npairs == 0) ? take(b * T * n * m * n) : 0;
     w.f_uu = (ddp && need_ux && npairs == 0) ? take(b * T * n * m * m) : 0;
+    w.idx = take((b + 1) / 2);   // int32 winner index per trajectory
+    w.tail_slots = ilqr_tail_slots(b);
+    w.scratch = take(w.tail_slots * (T + 1) * 256);   // all-store blocks (n = 12, m = 4 only): 16 step sizes x 16 doubles per step
     w.total = o;
     return w;
 }
@@ -156,6 +183,8 @@ extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* c
 
     double* f_ux = (need_ux && npairs == 0) ? ws + w.f_ux : nullptr;
     double* f_uu = (need_ux && npairs == 0) ? ws + w.f_uu : nullptr;
+    const bool can_all_store = w.tail_slots > 0 && zm::rollout_all_store_supported(model, cost, T);
+    int32_t* widx = (int32_t*)(ws + w.idx);
     int it = 0;
     int64_t count = batch;
     for (; it < max_iter; ++it) {                                                                        // (:301-303)
@@ -192,12 +221,21 @@ extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* c
                                            ws + w.v_x, ws + w.v_xx, list, count, active, 1, ws + w.l, L, batch, T, n, m, st);
         }
         if (rc) return rc;
-        rc = zm_rollout_linesearch_list_f64(model, cost, x0, ws + w.l, L, xTraj, uTraj, ws + w.alphas, 16, list, count, active,
-                                            ws + w.xT2, ws + w.uT2, ws + w.Jn, nullptr, batch, T, st);
-        if (rc) return rc;
-        // accept: converged = |J - J_new| <= tol, (traj, J) <- (traj_new, J_new) on the listed rows        (:316-320)
-        rc = zm_ilqr_accept_f64(list, count, J, ws + w.Jn, xTraj, ws + w.xT2, uTraj, ws + w.uT2, converged, active, tol, batch, T, n,
-                                m, st);
+        // 16-way line search (:116-150), then accept: converged = |J - J_new| <= tol, (traj, J) <- (traj_new, J_new) on the listed
+        // rows (:316-320)
+        if (can_all_store && count <= w.tail_slots) {
+            rc = zm::rollout_linesearch_all_store(model, cost, x0, ws + w.l, L, xTraj, uTraj, ws + w.alphas, list, count, active,
+                                                  ws + w.scratch, ws + w.Jn, widx, batch, T, st);
+            if (rc) return rc;
+            rc = zm::ilqr_accept(list, count, J, ws + w.Jn, xTraj, nullptr, uTraj, nullptr, converged, active, tol, batch, T, n, m, st,
+                                 ws + w.scratch, widx);
+        } else {
+            rc = zm_rollout_linesearch_list_f64(model, cost, x0, ws + w.l, L, xTraj, uTraj, ws + w.alphas, 16, list, count, active,
+                                                ws + w.xT2, ws + w.uT2, ws + w.Jn, nullptr, batch, T, st);
+            if (rc) return rc;
+            rc = zm_ilqr_accept_f64(list, count, J, ws + w.Jn, xTraj, ws + w.xT2, uTraj, ws + w.uT2, converged, active, tol, batch, T,
+                                    n, m, st);
+        }
         if (rc) return rc;
     }
     if (iterations) *iterations = it;

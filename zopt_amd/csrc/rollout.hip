@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64) void rollout_linesearch_kernel(const zm_model_t
 int rollout_fast_dispatch(const zm_model_t& md, const double* Q, const double* R, const double* Qf, int diagonal, const double* x0,
                           const double* l, const double* L, const double* xPrev, const double* uPrev,
                           const double* alphas, int n_alpha, const int* active, const int* list, int64_t count, double* xTraj,
-                          double* uTraj, double* J, int* idx, int64_t batch, int T, hipStream_t st);
+                          double* uTraj, double* J, int* idx, int64_t batch, int T, hipStream_t st, double* scratch);
 
 }  // namespace zm
 
@@ -143,7 +143,7 @@ static int rollout_impl(const zm_model_t* model, const zm_quadcost_t* cost, cons
                                          const double* l, const double* L, const double* xPrev, const double* uPrev,
                                          const double* alphas, int n_alpha, const int32_t* active, const int32_t* list,
                                          int64_t count, double* xTraj, double* uTraj, double* J, int32_t* alpha_idx,
-                                         int64_t batch, int T, void* stream) {
+                                         int64_t batch, int T, void* stream, double* scratch = nullptr) {
     if (!model || !x0 || !l || !L || !xPrev || !uPrev || !alphas || !xTraj || !uTraj)
         return zm::set_error(ZM_EINVAL, "zm_rollout_linesearch_f64: null pointer");
     if (batch < 0 || T < 0 || n_alpha < 1 || n_alpha > 16)
@@ -168,6 +168,7 @@ static int rollout_impl(const zm_model_t* model, const zm_quadcost_t* cost, cons
         return zm::set_error(ZM_EINVAL, "zm_rollout_linesearch_f64: cost needs Q, R, Qf");
     if (batch == 0 || (list && count == 0)) return ZM_OK;
     if (count < 0 || count > batch) return zm::set_error(ZM_EINVAL, "zm_rollout_linesearch: bad list length");
+    if (scratch && !(n_alpha == 16 && list && alpha_idx && J)) return zm::set_error(ZM_EINVAL, "rollout: all-store mode needs 16 step sizes, a list, J and alpha_idx");
     const int64_t nslot = list ? count : batch;
     hipStream_t st = (hipStream_t)stream;
     zm_quadcost_t cs = cost ? *cost : zm_quadcost_t{nullptr, nullptr, nullptr, 0, 0};
@@ -182,7 +183,8 @@ static int rollout_impl(const zm_model_t* model, const zm_quadcost_t* cost, cons
     //  redundant, and still several times faster than the generic lane-per-trajectory kernel with its uncoalesced policy reads)
     if (!force_generic && !windy && (n_alpha == 16 || n_alpha == 1) && md.n == 12 && md.m == 4 && cost && T >= 1)
         return zm::rollout_fast_dispatch(md, cs.Q, cs.R, cs.Qf, cs.diagonal, x0, l, L, xPrev, uPrev, alphas, n_alpha, act, (const int*)list, count, xTraj,
-                                         uTraj, J, (int*)alpha_idx, batch, T, st);
+                                         uTraj, J, (int*)alpha_idx, batch, T, st, scratch);
+    if (scratch) return zm::set_error(ZM_EUNSUPPORTED, "rollout: all-store mode needs the fast path");
     if (n_alpha == 1) {
         const unsigned blocks = (unsigned)((nslot + 63) / 64);
         hipLaunchKernelGGL((zm::rollout_linesearch_kernel<1>), dim3(blocks), dim3(64), 0, st, md, cs, hc, x0, l, L, xPrev,
@@ -216,6 +218,30 @@ extern "C" int zm_rollout_linesearch_list_f64(const zm_model_t* model, const zm_
                         batch, T, stream);
 }
 
+// Solver-internal (ilqr_solve.hip): the 16-way line search in all-store mode -- every step size's rollout goes to the scratch blocks
+// of its slot ((T+1) * 256 doubles per slot, layout in rollout_fast.hip), alpha_idx[t] names the winner, nothing is written to
+// xTraj / uTraj.
+namespace zm {
+bool rollout_all_store_supported(const zm_model_t* model, const zm_quadcost_t* cost, int T) {
+    if (!model || !cost || T < 1) return false;
+    static const bool force_generic = [] {
+        const char* e = getenv("ZOPT_AMD_ROLLOUT_PATH");
+        return e && e[0] == 'g';
+    }();
+    const bool windy = model->wind_ned[0] != 0.0 || model->wind_ned[1] != 0.0 || model->wind_ned[2] != 0.0;
+    const bool dims = model->kind == ZM_MODEL_QUADCOPTER || (model->kind == ZM_MODEL_LINEAR && model->n == 12 && model->m == 4);
+    return !force_generic && !windy && dims;
+}
+int rollout_linesearch_all_store(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0, const double* l, const double* L,
+                                 const double* xPrev, const double* uPrev, const double* alphas, const int32_t* list, int64_t count,
+                                 const int32_t* active, double* scratch, double* J, int32_t* alpha_idx, int64_t batch, int T,
+                                 void* stream) {
+    // (xTraj / uTraj are not written in this mode; the non-null placeholders only pass the argument check)
+    return rollout_impl(model, cost, x0, l, L, xPrev, uPrev, alphas, 16, active, list, count, scratch, scratch, J, alpha_idx, batch, T,
+                        stream, scratch);
+}
+}  // namespace zm
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Acceptance step of the iLQR / DDP loop for the trajectories of a compacted id list: take the line search's result
 // (trajectory, cost), test convergence and retire converged trajectories.  Replaces zopt/ilqrUtils.py:316-320
@@ -228,7 +254,8 @@ __global__ __launch_bounds__(256) void ilqr_accept_kernel(const int* __restrict_
                                                           double* __restrict__ xT, const double* __restrict__ xT2,
                                                           double* __restrict__ uT, const double* __restrict__ uT2,
                                                           int* __restrict__ converged, int* __restrict__ active,
-                                                          const double tol, const long xrow, const long urow) {
+                                                          const double tol, const long xrow, const long urow,
+                                                          const double* __restrict__ scratch, const int* __restrict__ idx) {
     const long slot = blockIdx.x;
     if (slot >= count) return;
     const long t = list[slot];
@@ -238,8 +265,23 @@ __global__ __launch_bounds__(256) void ilqr_accept_kernel(const int* __restrict_
     if (threadIdx.x == 0) act = active[t];   // the list may be older than the mask (it is rebuilt only every few iterations)
     __syncthreads();
     if (act == 0) return;
-    for (long e = threadIdx.x; e < xrow; e += blockDim.x) xT[t * xrow + e] = xT2[t * xrow + e];
-    for (long e = threadIdx.x; e < urow; e += blockDim.x) uT[t * urow + e] = uT2[t * urow + e];
+    // the new trajectory: row t of (xT2, uT2), or -- after an all-store line search (n = 12, m = 4) -- the winner's 16-byte pieces
+    // of this slot's scratch blocks (layout: rollout_fast.hip, allstore)
+    if (scratch) {
+        constexpr int n = 12, m = 4, PB = (n + m) / 2;
+        const double* sb = scratch + slot * (xrow / n) * (PB * 32) + idx[t] * 2;
+        for (long e = threadIdx.x; e < xrow; e += blockDim.x) {
+            const long k = e / n, i = e % n;
+            xT[t * xrow + e] = sb[(k * PB + (i >> 1)) * 32 + (i & 1)];
+        }
+        for (long e = threadIdx.x; e < urow; e += blockDim.x) {
+            const long k = e / m, i = e % m;
+            uT[t * urow + e] = sb[((k + 1) * PB + n / 2 + (i >> 1)) * 32 + (i & 1)];
+        }
+    } else {
+        for (long e = threadIdx.x; e < xrow; e += blockDim.x) xT[t * xrow + e] = xT2[t * xrow + e];
+        for (long e = threadIdx.x; e < urow; e += blockDim.x) uT[t * urow + e] = uT2[t * urow + e];
+    }
     if (threadIdx.x == 0) {
         const double jn = Jn[t];
         const int cv = (__builtin_fabs(J[t] - jn) <= tol) ? 1 : 0;   // NaN compares false: never "converged"
@@ -250,16 +292,26 @@ __global__ __launch_bounds__(256) void ilqr_accept_kernel(const int* __restrict_
 }
 }  // namespace zm
 
+namespace zm {
+int ilqr_accept(const int32_t* list, int64_t count, double* J, const double* Jn, double* xTraj, const double* xTrajNew, double* uTraj,
+                const double* uTrajNew, int32_t* converged, int32_t* active, double tol, int64_t batch, int T, int n, int m,
+                void* stream, const double* scratch, const int32_t* idx) {
+    if (batch == 0 || count == 0) return ZM_OK;
+    if (!list || !J || !Jn || !xTraj || !uTraj || !converged || !active || (scratch ? !idx : (!xTrajNew || !uTrajNew)))
+        return set_error(ZM_EINVAL, "zm_ilqr_accept_f64: null pointer");
+    if (count < 0 || count > batch || T < 1 || n < 1 || m < 1) return set_error(ZM_EINVAL, "zm_ilqr_accept_f64: bad size");
+    if (scratch && (n != 12 || m != 4)) return set_error(ZM_EUNSUPPORTED, "ilqr_accept: all-store scratch is laid out for n = 12, m = 4");
+    hipLaunchKernelGGL(ilqr_accept_kernel, dim3((unsigned)count), dim3(256), 0, (hipStream_t)stream, (const int*)list,
+                       (long)count, J, Jn, xTraj, xTrajNew, uTraj, uTrajNew, (int*)converged, (int*)active, tol,
+                       (long)(T + 1) * n, (long)T * m, scratch, (const int*)idx);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+}  // namespace zm
+
 extern "C" int zm_ilqr_accept_f64(const int32_t* list, int64_t count, double* J, const double* Jn, double* xTraj,
                                   const double* xTrajNew, double* uTraj, const double* uTrajNew, int32_t* converged,
                                   int32_t* active, double tol, int64_t batch, int T, int n, int m, void* stream) {
-    if (batch == 0 || count == 0) return ZM_OK;
-    if (!list || !J || !Jn || !xTraj || !xTrajNew || !uTraj || !uTrajNew || !converged || !active)
-        return zm::set_error(ZM_EINVAL, "zm_ilqr_accept_f64: null pointer");
-    if (count < 0 || count > batch || T < 1 || n < 1 || m < 1) return zm::set_error(ZM_EINVAL, "zm_ilqr_accept_f64: bad size");
-    hipLaunchKernelGGL(zm::ilqr_accept_kernel, dim3((unsigned)count), dim3(256), 0, (hipStream_t)stream, (const int*)list,
-                       (long)count, J, Jn, xTraj, xTrajNew, uTraj, uTrajNew, (int*)converged, (int*)active, tol,
-                       (long)(T + 1) * n, (long)T * m);
-    ZM_HIP_CHECK(hipGetLastError());
-    return ZM_OK;
+    return zm::ilqr_accept(list, count, J, Jn, xTraj, xTrajNew, uTraj, uTrajNew, converged, active, tol, batch, T, n, m, stream,
+                           nullptr, nullptr);
 }

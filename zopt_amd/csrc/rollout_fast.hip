@@ -7,7 +7,10 @@
 //    (the generic kernel issued 68 redundant global loads per lane and step);
 //  * cost matrices (and A, B of a linear model) live in LDS; diagonal Q, R, Qf (the demos' weights) use 12 + 4 FMAs;
 //  * the alpha = 1 lane stores its rollout speculatively during pass 1: pass 2 (re-roll of the winner) only runs for
-//    trajectories whose argmin is another step size.
+//    trajectories whose argmin is another step size;
+//  * "all-store" mode (FastArgs::scratch, used by the solvers once few trajectories are left and a launch lasts as long as its
+//    slowest wave's 2 x T dependent steps): EVERY lane stores its rollout into a scratch row [slot][step size], no second pass at
+//    all -- the accept step copies the winner's row.  16x the stores, half the chain.
 #include "models.h"
 #include "zm_common.h"
 
@@ -39,7 +42,15 @@ struct FastArgs {
     long batch;
     int T;
     int n_alpha;       // 16, or 1: every lane of a trajectory's group rolls the same step size (lane 0 stores; no second pass)
+    double* scratch;   // all-store mode (else nullptr): per slot (T+1) blocks of ALLSTORE_BLOCK doubles, see allstore_offset()
 };
+
+// All-store scratch layout: the 16 lanes of a trajectory write NEIGHBOURING 16-byte pieces, so that one store instruction of a group
+// covers 256 contiguous bytes (a row per step size instead -- 12.9 KB apart -- makes every store touch 64 different lines per wave
+// and lengthens the chain by 40 %).  Block kb of a slot holds x_kb (pairs 0..5) and u_{kb-1} (pairs 6, 7; unused in block 0):
+//     scratch[((slot * (T+1) + kb) * 8 + pair) * 32 + a * 2 + {0, 1}]          (8 pairs x 16 step sizes x 2 doubles per block)
+constexpr int ALLSTORE_PAIRS = (RN + RM) / 2, ALLSTORE_BLOCK = ALLSTORE_PAIRS * 32;
+
 
 template <int KIND>
 __device__ __forceinline__ void fast_step(const double* As, const double* Bs, const double dt,
@@ -119,7 +130,7 @@ struct PolPtrs {
     int st[5];
 };
 
-template <int KIND, bool DIAG>
+template <int KIND, bool DIAG, bool ALL>
 // (no __restrict__ on the LDS tables: with it the loop-invariant LDS reads of Q, A, B ... are hoisted into registers --
 //  several hundred VGPRs -- instead of being re-read by broadcast every step)
 __device__ __forceinline__ void rollout_ls_body(const FastArgs& g, const double* Qs, const double* Rs, const double* Qfs,
@@ -164,6 +175,7 @@ __device__ __forceinline__ void rollout_ls_body(const FastArgs& g, const double*
     const double* x0t = g.x0 + t * RN;
     double* xo = g.xTraj + t * (T + 1) * RN;
     double* uo = g.uTraj + t * T * RM;
+    double* so = ALL ? g.scratch + (live ? slot : 0) * (long)(T + 1) * ALLSTORE_BLOCK + a * 2 : nullptr;
 
     // one rollout of step size `al`; STORE: this lane writes xTraj / uTraj
     auto rollout = [&](const double al, const bool store) -> double {
@@ -171,8 +183,13 @@ __device__ __forceinline__ void rollout_ls_body(const FastArgs& g, const double*
 #pragma unroll
         for (int i = 0; i < RN; ++i) x[i] = x0t[i];
         if (store) {
+            if constexpr (ALL) {
 #pragma unroll
-            for (int i = 0; i < RN; ++i) xo[i] = x[i];
+                for (int i = 0; i < RN; ++i) so[(i >> 1) * 32 + (i & 1)] = x[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < RN; ++i) xo[i] = x[i];
+            }
         }
         // stage step 0
         {
@@ -214,10 +231,18 @@ __device__ __forceinline__ void rollout_ls_body(const FastArgs& g, const double*
 #pragma unroll
             for (int i = 0; i < RN; ++i) x[i] = xn[i];
             if (store) {
+                if constexpr (ALL) {
+                    double* sb = so + (long)(k + 1) * ALLSTORE_BLOCK;
 #pragma unroll
-                for (int i = 0; i < RM; ++i) uo[(long)k * RM + i] = u[i];
+                    for (int i = 0; i < RN; ++i) sb[(i >> 1) * 32 + (i & 1)] = x[i];
 #pragma unroll
-                for (int i = 0; i < RN; ++i) xo[(long)(k + 1) * RN + i] = x[i];
+                    for (int i = 0; i < RM; ++i) sb[(RN / 2 + (i >> 1)) * 32 + (i & 1)] = u[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < RM; ++i) uo[(long)k * RM + i] = u[i];
+#pragma unroll
+                    for (int i = 0; i < RN; ++i) xo[(long)(k + 1) * RN + i] = x[i];
+                }
             }
             if (more) {
 #pragma unroll
@@ -234,7 +259,7 @@ __device__ __forceinline__ void rollout_ls_body(const FastArgs& g, const double*
     // pass 0: every lane its own step size; lane a == 0 (alpha_0) stores speculatively.
     // pass 1 (only where another step size than alpha_0 won): every lane of the group re-rolls the winner, lane 0 stores.
     double al = alpha;
-    bool store = live && a == 0;
+    bool store = live && (a == 0 || ALL);
     for (int pass = 0; pass < 2; ++pass) {
         const double J = rollout(al, store);
         if (pass == 1) break;
@@ -257,7 +282,7 @@ __device__ __forceinline__ void rollout_ls_body(const FastArgs& g, const double*
             if (g.J) g.J[t] = Jbest;
             if (g.idx) g.idx[t] = best;
         }
-        const bool need2 = live && best != 0;
+        const bool need2 = live && best != 0 && !ALL;
         if (__ballot(need2) == 0ull) break;
         al = g.alphas[best];
         store = need2 && a == 0;
@@ -267,7 +292,7 @@ __device__ __forceinline__ void rollout_ls_body(const FastArgs& g, const double*
 // DIAG_ONLY: the caller asserted diagonal weights (zm_quadcost_t.diagonal): only the diagonal path is compiled in -- 158 VGPRs, three
 // waves per SIMD.  Otherwise the kernel decides per launch; it then also carries the general path, whose hoisted weight matrices
 // cost it 458 registers (one wave per SIMD) on either branch.
-template <int KIND, bool DIAG_ONLY>
+template <int KIND, bool DIAG_ONLY, bool ALL>
 __global__ __launch_bounds__(64) void rollout_ls_fast_kernel(const FastArgs g) {
     __shared__ double Qs[RN * RN], Rs[RM * RM], Qfs[RN * RN];
     __shared__ double As[KIND == ZM_MODEL_LINEAR ? RN * RN : 1], Bs[KIND == ZM_MODEL_LINEAR ? RN * RM : 1];
@@ -291,13 +316,13 @@ __global__ __launch_bounds__(64) void rollout_ls_fast_kernel(const FastArgs g) {
     }
     __syncthreads();
     if constexpr (DIAG_ONLY) {
-        rollout_ls_body<KIND, true>(g, Qs, Rs, Qfs, As, Bs, pol);
+        rollout_ls_body<KIND, true, ALL>(g, Qs, Rs, Qfs, As, Bs, pol);
     } else {
         // diagonal weights (the demos' Q = I, R = I, Qf = 10 I): x^T W x costs n FMAs instead of n^2; wave-uniform
         if (__ballot(offdiag) == 0ull)
-            rollout_ls_body<KIND, true>(g, Qs, Rs, Qfs, As, Bs, pol);
+            rollout_ls_body<KIND, true, ALL>(g, Qs, Rs, Qfs, As, Bs, pol);
         else
-            rollout_ls_body<KIND, false>(g, Qs, Rs, Qfs, As, Bs, pol);
+            rollout_ls_body<KIND, false, ALL>(g, Qs, Rs, Qfs, As, Bs, pol);
     }
 }
 
@@ -305,10 +330,16 @@ template <int KIND>
 static int launch_fast(const FastArgs& g, const bool diag_only, hipStream_t st) {
     const long nslot = g.list ? g.count : g.batch;
     const dim3 grid((unsigned)((nslot + 3) / 4)), block(64);
-    if (diag_only)
-        hipLaunchKernelGGL((rollout_ls_fast_kernel<KIND, true>), grid, block, 0, st, g);
-    else
-        hipLaunchKernelGGL((rollout_ls_fast_kernel<KIND, false>), grid, block, 0, st, g);
+    if (g.scratch) {
+        if (diag_only)
+            hipLaunchKernelGGL((rollout_ls_fast_kernel<KIND, true, true>), grid, block, 0, st, g);
+        else
+            hipLaunchKernelGGL((rollout_ls_fast_kernel<KIND, false, true>), grid, block, 0, st, g);
+    } else if (diag_only) {
+        hipLaunchKernelGGL((rollout_ls_fast_kernel<KIND, true, false>), grid, block, 0, st, g);
+    } else {
+        hipLaunchKernelGGL((rollout_ls_fast_kernel<KIND, false, false>), grid, block, 0, st, g);
+    }
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }
@@ -317,9 +348,9 @@ static int launch_fast(const FastArgs& g, const bool diag_only, hipStream_t st) 
 int rollout_fast_dispatch(const zm_model_t& md, const double* Q, const double* R, const double* Qf, int diagonal,
                           const double* x0, const double* l, const double* L, const double* xPrev, const double* uPrev,
                           const double* alphas, int n_alpha, const int* active, const int* list, int64_t count, double* xTraj,
-                          double* uTraj, double* J, int* idx, int64_t batch, int T, hipStream_t st) {
+                          double* uTraj, double* J, int* idx, int64_t batch, int T, hipStream_t st, double* scratch) {
     FastArgs g{md.A, md.B, md.dt, Q, R, Qf, x0, l, L, xPrev, uPrev, alphas, active, list, (long)count, xTraj, uTraj, J, idx,
-               (long)batch, T, n_alpha};
+               (long)batch, T, n_alpha, scratch};
     if (md.kind == ZM_MODEL_QUADCOPTER) return launch_fast<ZM_MODEL_QUADCOPTER>(g, diagonal == 1, st);
     return launch_fast<ZM_MODEL_LINEAR>(g, diagonal == 1, st);
 }
