@@ -1,0 +1,39 @@
+// Host build of the generated closed-form quadcopter derivatives (zopt_amd/csrc/quad_derivs_gen.h) for tests/test_quad_derivs.py:
+// the same header the kernels include, compiled by g++ so that the formulas can be checked against the oracle without a GPU.
+#include <cmath>
+
+#include "../zopt_amd/csrc/quad_derivs_gen.h"
+
+static zm::QuadAtoms atoms(const double* x, const double* u, const double* w) {
+    zm::QuadAtoms a;
+    for (int i = 0; i < 12; ++i) a.x[i] = x[i];
+    a.u0 = u[0];
+    for (int i = 0; i < 3; ++i) a.w[i] = w[i];
+    a.s6 = std::sin(x[6]); a.c6 = std::cos(x[6]);
+    a.s7 = std::sin(x[7]); a.c7 = std::cos(x[7]);
+    a.s8 = std::sin(x[8]); a.c8 = std::cos(x[8]);
+    a.ic7 = 1.0 / a.c7;
+    return a;
+}
+
+// still_air != 0: the WIND = false instantiation (the caller passes w = 0)
+extern "C" void quad_jacobian(const double* x, const double* u, const double* w, int still_air, double* J /* (12, 16) */) {
+    const zm::QuadAtoms a = atoms(x, u, w);
+    for (int j = 0; j < 16; ++j) {
+        double o[12];
+        if (still_air) zm::quad_jac_column<false>(j, a, o);
+        else zm::quad_jac_column<true>(j, a, o);
+        for (int i = 0; i < 12; ++i) J[i * 16 + j] = o[i];
+    }
+}
+
+extern "C" void quad_hessian_pairs(const double* x, const double* u, const double* w, int still_air, int npairs,
+                                   double* H /* (npairs, 12) */) {
+    const zm::QuadAtoms a = atoms(x, u, w);
+    for (int p = 0; p < npairs; ++p) {
+        double o[12];
+        if (still_air) zm::quad_hess_pair<false>(p, a, o);
+        else zm::quad_hess_pair<true>(p, a, o);
+        for (int i = 0; i < 12; ++i) H[p * 12 + i] = o[i];
+    }
+}

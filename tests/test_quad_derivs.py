@@ -1,0 +1,117 @@
+"""The generated closed-form derivatives of the quadcopter (zopt_amd/csrc/quad_derivs_gen.h, tools/gen_quad_derivs.py) against the
+oracle's model on the CPU: first derivatives vs complex-step differentiation of oracle.quad_inertialDynamics, second derivatives
+vs torch autograd of the oracle's torch restatement -- with and without wind; plus: the header in the tree is what the generator
+produces (nobody edited one without the other)."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import zopt_oracle as zo  # noqa: E402
+
+PAIRS = [0x00, 0x11, 0x22, 0x24, 0x15, 0x05, 0x23, 0x13, 0x04, 0x66, 0x67, 0x77, 0x68, 0x78, 0x88, 0x06, 0x07, 0x08, 0x16, 0x17, 0x18,
+         0x26, 0x27, 0x28, 0x46, 0x47, 0x56, 0x57]
+
+
+@pytest.fixture(scope="module")
+def shim(tmp_path_factory):
+    so = tmp_path_factory.mktemp("quad_derivs") / "quad_derivs_shim.so"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-o", str(so),
+                    os.path.join(ROOT, "tests", "quad_derivs_shim.cpp")], check=True)
+    lib = ctypes.CDLL(str(so))
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.quad_jacobian.argtypes = [dp, dp, dp, ctypes.c_int, dp]
+    lib.quad_hessian_pairs.argtypes = [dp, dp, dp, ctypes.c_int, ctypes.c_int, dp]
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _points(seed, count):
+    rng = np.random.default_rng(seed)
+    for _ in range(count):
+        x = rng.standard_normal(12) * np.array([3, 3, 3, 1, 1, 1, 0.6, 0.6, 2.0, 5, 5, 5])
+        u = np.array([9.807, 0, 0, 0]) + rng.standard_normal(4)
+        yield x, u
+
+
+@pytest.mark.parametrize("wind", [(0.0, 0.0, 0.0), (3.0, 1.0, -0.5)])
+def test_first_derivatives_match_complex_step(shim, wind):
+    w = np.array(wind)
+    for x, u in _points(1, 20):
+        ref = _complex_step_jacobian(x, u, w)
+        for still_air in ([0, 1] if not np.any(w) else [0]):      # w = 0: the general form and the still-air form
+            J = np.zeros((12, 16))
+            shim.quad_jacobian(_p(x), _p(u), _p(w), still_air, _p(J))
+            assert np.max(np.abs(J - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
+
+
+def _complex_step_jacobian(x, u, w):
+    ref = np.zeros((12, 16))
+    h = 1e-30
+    for j in range(16):
+        z = np.concatenate([x, u]).astype(complex)
+        z[j] += 1j * h
+        ref[:, j] = np.imag(zo.quad_inertialDynamics(z[:12], z[12:], w)) / h
+    return ref
+
+
+def test_second_derivatives_match_autograd_and_nothing_else_is_nonzero(shim):
+    import torch
+    w = np.zeros(3)
+    f = zo.quad_euler_step_torch(1.0)                          # x + 1.0 * xd: the second derivatives of xd
+    for x, u in _points(2, 6):
+        H = np.zeros((len(PAIRS), 12))
+        H1 = np.zeros((len(PAIRS), 12))
+        shim.quad_hessian_pairs(_p(x), _p(u), _p(w), 1, len(PAIRS), _p(H))
+        shim.quad_hessian_pairs(_p(x), _p(u), _p(w), 0, len(PAIRS), _p(H1))
+        assert np.max(np.abs(H - H1)) <= 1e-13 * max(1.0, np.max(np.abs(H)))      # still-air form == general form at w = 0
+        z = torch.tensor(np.concatenate([x, u]), dtype=torch.float64)
+        hes = torch.stack([torch.autograd.functional.hessian(lambda zz, i=i: f(zz[:12], zz[12:])[i], z) for i in range(12)]).numpy()
+        seen = np.zeros((16, 16), bool)
+        for p, ab in enumerate(PAIRS):
+            a, b = ab >> 4, ab & 15
+            seen[a, b] = seen[b, a] = True
+            assert np.max(np.abs(H[p] - hes[:, a, b])) <= 1e-11 * max(1.0, np.max(np.abs(hes))), (p, a, b)
+        assert np.max(np.abs(hes[:, ~seen])) == 0.0          # every undeclared pair: exactly zero
+
+
+def test_second_derivatives_with_wind_match_differences_of_the_jacobian(shim):
+    """the oracle's torch model has no wind: central differences of the complex-step Jacobian instead (error ~ h^2)"""
+    w = np.array([3.0, 1.0, -0.5])
+    h = 1e-5
+    for x, u in _points(3, 4):
+        H = np.zeros((len(PAIRS), 12))
+        shim.quad_hessian_pairs(_p(x), _p(u), _p(w), 0, len(PAIRS), _p(H))
+        z = np.concatenate([x, u])
+        full = np.zeros((12, 16, 16))
+        for b in range(16):
+            zp, zm = z.copy(), z.copy()
+            zp[b] += h
+            zm[b] -= h
+            full[:, :, b] = (_complex_step_jacobian(zp[:12], zp[12:], w) - _complex_step_jacobian(zm[:12], zm[12:], w)) / (2 * h)
+        seen = np.zeros((16, 16), bool)
+        scale = max(1.0, np.max(np.abs(full)))
+        for p, ab in enumerate(PAIRS):
+            a, b = ab >> 4, ab & 15
+            seen[a, b] = seen[b, a] = True
+            assert np.max(np.abs(H[p] - full[:, a, b])) <= 1e-7 * scale, (p, a, b)
+        assert np.max(np.abs(full[:, ~seen])) <= 1e-7 * scale
+
+
+def test_header_is_what_the_generator_writes(tmp_path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_quad_derivs", os.path.join(ROOT, "tools", "gen_quad_derivs.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert gen.PAIRS == PAIRS
+    src = open(os.path.join(ROOT, "zopt_amd", "csrc", "models.h")).read()
+    for ab in PAIRS:                                         # the generator's pair table is models.h's
+        assert f"0x{ab:02x}" in src.lower()

@@ -73,6 +73,9 @@ static long ilqr_tail_slots(long batch) {
     return thr < 0 ? 0 : (thr < batch ? thr : batch);
 }
 
+int expand_list(const zm_model_t* model, const zm_quadcost_t* cost, const double* xTraj, const double* uTraj, const int32_t* list,
+                int64_t count, const int32_t* active, double* f_x, double* f_u, double* c_x, double* c_u, double* v_x, int64_t batch,
+                int T, void* stream);
 bool rollout_all_store_supported(const zm_model_t* model, const zm_quadcost_t* cost, int T);
 int rollout_linesearch_all_store(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0, const double* l, const double* L,
                                  const double* xPrev, const double* uPrev, const double* alphas, const int32_t* list, int64_t count,
@@ -197,10 +200,9 @@ extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* c
             count = hcount;
             if (count == 0) break;
         }
-        rc = zm_linearize_dynamics_list_f64(model, xTraj, uTraj, list, count, active, nullptr, ws + w.f_x, ws + w.f_u, batch, T, st);
-        if (rc) return rc;
-        rc = zm_quadratize_cost_list_f64(cost, n, m, xTraj, uTraj, list, count, active, nullptr, ws + w.c_x, ws + w.c_u, nullptr,
-                                         ws + w.v_x, nullptr, nullptr, nullptr, nullptr, batch, T, st);
+        // expansions along the current trajectories: [f_x | f_u], c_x, c_u, v_x in one launch                  (:304-313)
+        rc = zm::expand_list(model, cost, xTraj, uTraj, list, count, active, ws + w.f_x, ws + w.f_u, ws + w.c_x, ws + w.c_u,
+                             ws + w.v_x, batch, T, st);
         if (rc) return rc;
         if (ddp && npairs > 0) {
             // packed second derivatives: 28 x 12 doubles per point for the quadcopter instead of the zero-filled (n,n,n) tensors

@@ -10,51 +10,166 @@
 // quadratize_cost: c_x = (Q+Q^T)x, c_u = (R+R^T)u, c = x^TQx + u^TRu per point; the Hessians Q+Q^T, R+R^T, Qf+Qf^T
 // are trajectory-independent and written once.
 #include "models.h"
+#include "quad_derivs_gen.h"
 #include "zm_common.h"
 
 namespace zm {
 
-__global__ __launch_bounds__(64) void linearize_dynamics_kernel(const zm_model_t md, const double* __restrict__ xTraj,
+// what the generated closed forms of the quadcopter's derivatives read (quad_derivs_gen.h): state, thrust, wind, one sincos per angle
+__device__ __forceinline__ QuadAtoms quad_atoms(const zm_model_t& md, const double* xk, const double* uk) {
+    QuadAtoms a;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) a.x[i] = xk[i];
+    a.u0 = uk[0];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a.w[i] = md.wind_ned[i];
+    zm_sincos(a.x[6], &a.s6, &a.c6);
+    zm_sincos(a.x[7], &a.s7, &a.c7);
+    zm_sincos(a.x[8], &a.s8, &a.c8);
+    a.ic7 = 1.0 / a.c7;
+    return a;
+}
+
+// Optional fused cost expansion (the solvers' per-iteration call, zm::expand_list): the lane of variable j also writes
+// c_x[j] = ((Q + Q^T) x)[j] resp. c_u[j - n] = ((R + R^T) u)[j - n] of its point, and the lanes of a trajectory's last point the
+// terminal gradient v_x = (Qf + Qf^T) x_T -- the same expressions, in the same order, as quadratize_cost_kernel.
+struct ExpandCost {
+    zm_quadcost_t cs;
+    double* c_x;
+    double* c_u;
+    double* v_x;
+};
+
+// Launch shape of the expansion kernels: 16 lanes per trajectory point, LIN_WAVES waves per workgroup.  Measured on the stand-alone
+// copy of this kernel (tools/lin_lab.hip, profiles/r02_lin_lab*.txt): with the closed forms in their first, fully expanded shape the
+// launch was bound by their ~700 fp64 operations per wave (as the dual-number evaluation before them), not by memory -- without
+// loads AND stores it took as long; one-wave or four-wave workgroups, one point or several per group, whole-line or column-strided
+// stores moved it by less than 10 %.  With the factored forms it writes its 1 536 B per point at the rate HBM takes them.
+constexpr int LIN_WAVES = 4;
+template <bool COST, bool QUAD>
+__global__ __launch_bounds__(64 * LIN_WAVES, 3) void linearize_dynamics_kernel(const zm_model_t md, const double* __restrict__ xTraj,
                                                                 const double* __restrict__ uTraj,
                                                                 const int* __restrict__ active, double* __restrict__ f,
                                                                 double* __restrict__ f_x, double* __restrict__ f_u,
                                                                 const long batch, const int T,
-                                                                const int* __restrict__ list, const long count) {
+                                                                const int* __restrict__ list, const long count, const ExpandCost ec) {
+    // one point's [f_x (n, n) | f_u (n, m)] image per 16-lane group: the columns the lanes computed are transposed here so that the
+    // group stores whole 128-byte lines instead of column-strided 8-byte pieces
+    __shared__ double tile[4 * LIN_WAVES][MAXN * (MAXN + MAXM)];
     const int lane = threadIdx.x;
     const int j = lane & 15;                                   // seed direction / Jacobian column
-    const long sp = (long)blockIdx.x * 4 + (lane >> 4);        // slot * T + k; slots are the listed trajectories, or all of them
+    const int q = lane >> 4;                                   // group of this workgroup
+    const long gi = (long)blockIdx.x * (4 * LIN_WAVES) + q;    // slot * T + k; slots are the listed trajectories, or all of them
     const long nslot = list ? count : batch;
-    if (sp >= nslot * T) return;
-    const long slot = sp / T;
-    const int k = (int)(sp - slot * T);
+    if (gi >= nslot * T) return;
+    const long slot = gi / T;
+    const int k = (int)(gi - slot * T);
     const long traj = list ? (long)list[slot] : slot;
-    if (active && active[traj] == 0) return;
+    const int n = QUAD ? 12 : md.n, m = QUAD ? 4 : md.m;   // (compile-time in the quadcopter variant)
     const long pt = traj * T + k;                              // point index
-    const int n = md.n, m = md.m;
-    if (j >= n + m) return;
+    double xv[MAXN], uv[MAXM];
     const double* xk = xTraj + (traj * (T + 1) + k) * n;
-    const double* uk = uTraj + pt * m;
-    Dual x[MAXN], u[MAXM], xn[MAXN];
+    {   // the point's loads go out together with the mask's
+        const double* uk = uTraj + pt * m;
 #pragma unroll
-    for (int i = 0; i < MAXN; ++i) x[i] = Dual{(i < n) ? xk[i] : 0.0, (i == j) ? 1.0 : 0.0};
+        for (int i = 0; i < MAXN; ++i) xv[i] = (i < n) ? xk[i] : 0.0;
 #pragma unroll
-    for (int i = 0; i < MAXM; ++i) u[i] = Dual{(i < m) ? uk[i] : 0.0, (n + i == j) ? 1.0 : 0.0};
-    model_step<Dual>(md, x, u, xn);
-    if (j < n) {
-        double* o = f_x + pt * n * n + j;
-#pragma unroll
-        for (int i = 0; i < MAXN; ++i)
-            if (i < n) o[i * n] = xn[i].d;
-    } else {
-        double* o = f_u + pt * n * m + (j - n);
-#pragma unroll
-        for (int i = 0; i < MAXN; ++i)
-            if (i < n) o[i * m] = xn[i].d;
+        for (int i = 0; i < MAXM; ++i) uv[i] = (i < m) ? uk[i] : 0.0;
     }
-    if (f && j == 0) {
+    if (active && active[traj] == 0) return;
+    {
+        // (the cost part first: its weight loads leave with the state's, ahead of the LDS exchange below -- a compiler barrier)
+        if constexpr (COST) {
+            const zm_quadcost_t& cs = ec.cs;
+            if (j < n) {
+                double g;
+                if (cs.diagonal == 1) {
+                    double xj = 0.0;
 #pragma unroll
-        for (int i = 0; i < MAXN; ++i)
-            if (i < n) f[pt * n + i] = xn[i].v;
+                    for (int i = 0; i < MAXN; ++i) xj = (i == j) ? xv[i] : xj;
+                    g = (cs.Q[j * n + j] + cs.Q[j * n + j]) * xj;
+                } else {
+                    g = 0.0;
+#pragma unroll
+                    for (int i = 0; i < MAXN; ++i)
+                        if (i < n) g = __builtin_fma(cs.Q[j * n + i] + cs.Q[i * n + j], xv[i], g);
+                }
+                ec.c_x[pt * n + j] = g;
+                if (k == T - 1) {   // terminal gradient from x_T
+                    const double* xT = xk + n;
+                    double gv;
+                    if (cs.diagonal == 1) {
+                        gv = (cs.Qf[j * n + j] + cs.Qf[j * n + j]) * xT[j];
+                    } else {
+                        gv = 0.0;
+                        for (int i = 0; i < n; ++i) gv = __builtin_fma(cs.Qf[j * n + i] + cs.Qf[i * n + j], xT[i], gv);
+                    }
+                    ec.v_x[traj * n + j] = gv;
+                }
+            } else if (j < n + m) {
+                const int ju = j - n;
+                double g;
+                if (cs.diagonal == 1) {
+                    double uj = 0.0;
+#pragma unroll
+                    for (int i = 0; i < MAXM; ++i) uj = (i == ju) ? uv[i] : uj;
+                    g = (cs.R[ju * m + ju] + cs.R[ju * m + ju]) * uj;
+                } else {
+                    g = 0.0;
+#pragma unroll
+                    for (int i = 0; i < MAXM; ++i)
+                        if (i < m) g = __builtin_fma(cs.R[ju * m + i] + cs.R[i * m + ju], uv[i], g);
+                }
+                ec.c_u[pt * m + ju] = g;
+            }
+        }
+        double col[MAXN];                                      // column j of [f_x | f_u] (lanes j >= n + m: unused)
+        if constexpr (QUAD) {
+            // closed-form column j of d xd / d z (generated, quad_derivs_gen.h): the trigonometric values once, a few operations
+            // per entry -- instead of the whole model on dual numbers per column.  x+ = x + dt xd  =>  column of [f_x | f_u] =
+            // e_j + dt d xd  (dt = 0: the derivative of xd itself, as model_step defines that case).
+            const QuadAtoms a = quad_atoms(md, xv, uv);
+            double o[12];
+            if (md.wind_ned[0] == 0.0 && md.wind_ned[1] == 0.0 && md.wind_ned[2] == 0.0) quad_jac_column<false>(j, a, o);   // still air
+            else quad_jac_column<true>(j, a, o);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) col[i] = (md.dt == 0.0) ? o[i] : __builtin_fma(md.dt, o[i], (i == j) ? 1.0 : 0.0);
+            if (f && j == 0) {   // model_step's quadcopter branch, spelled out (the generic call drags the linear model's A, B loads
+                                 // into this loop as invariants)
+                double xd[12];
+                quad_inertial_dynamics<double>(xv, uv, md.wind_ned, xd);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) f[pt * 12 + i] = (md.dt == 0.0) ? xd[i] : xv[i] + md.dt * xd[i];
+            }
+        } else {
+            Dual x[MAXN], u[MAXM], xn[MAXN];
+#pragma unroll
+            for (int i = 0; i < MAXN; ++i) x[i] = Dual{xv[i], (i == j) ? 1.0 : 0.0};
+#pragma unroll
+            for (int i = 0; i < MAXM; ++i) u[i] = Dual{uv[i], (n + i == j) ? 1.0 : 0.0};
+            model_step<Dual>(md, x, u, xn);
+#pragma unroll
+            for (int i = 0; i < MAXN; ++i) col[i] = xn[i].d;
+            if (f && j == 0) {
+#pragma unroll
+                for (int i = 0; i < MAXN; ++i)
+                    if (i < n) f[pt * n + i] = xn[i].v;
+            }
+        }
+        if (j < n + m) {
+            double* t = tile[q] + ((j < n) ? j : n * n + (j - n));
+            const int st = (j < n) ? n : m;
+#pragma unroll
+            for (int i = 0; i < MAXN; ++i)
+                if (i < n) t[i * st] = col[i];
+        }
+        wave_lds_sync();
+        {
+            double* ox = f_x + pt * n * n;
+            double* ou = f_u + pt * n * m;
+            for (int e = j; e < n * n; e += 16) ox[e] = tile[q][e];
+            for (int e = j; e < n * m; e += 16) ou[e] = tile[q][n * n + e];
+        }
     }
 }
 
@@ -150,7 +265,7 @@ __global__ __launch_bounds__(64) void quadratic_dynamics_kernel(const zm_model_t
 // DDP sweep (zm_ddp_backward_pairs_list_f64), whose contraction sum_i v_x[i] H[p][i] runs in the same order as over the full
 // tensors: bitwise the same result.
 template <int PPW>
-__global__ __launch_bounds__(64) void quadratic_dynamics_pairs_kernel(const zm_model_t md, const double* __restrict__ xTraj,
+__global__ __launch_bounds__(64 * LIN_WAVES) void quadratic_dynamics_pairs_kernel(const zm_model_t md, const double* __restrict__ xTraj,
                                                                       const double* __restrict__ uTraj,
                                                                       const int* __restrict__ active, double* __restrict__ H,
                                                                       const long batch, const int T,
@@ -158,7 +273,7 @@ __global__ __launch_bounds__(64) void quadratic_dynamics_pairs_kernel(const zm_m
     constexpr int LPP = 64 / PPW;                       // lanes per point
     const int sub = threadIdx.x / LPP, lp = threadIdx.x % LPP;
     const long nslot = list ? count : batch;
-    const long sp = (long)blockIdx.x * PPW + sub;       // slot * T + k
+    const long sp = (long)blockIdx.x * (PPW * LIN_WAVES) + sub;       // slot * T + k  (LIN_WAVES waves per workgroup, as linearize)
     if (sp >= nslot * T) return;
     const long slot = sp / T;
     const int k = (int)(sp - slot * T);
@@ -170,17 +285,36 @@ __global__ __launch_bounds__(64) void quadratic_dynamics_pairs_kernel(const zm_m
     const double* uk = uTraj + pt * m;
     int a = 0, b = 0;
     const int npairs = model_hessian_pairs(md, lp, a, b);
-    if (lp >= npairs) return;
-    double* o = H + (pt * npairs + lp) * n;
-    Hyper x[MAXN], u[MAXM], xn[MAXN];
+    // the pairs' rows are gathered in LDS and leave as whole lines (a row per lane -- 96 B apart -- reached HBM as partial-line writes)
+    __shared__ double tile[PPW * LIN_WAVES][ZM_MAX_PAIRS * MAXN];
+    double h[MAXN];
+    if (md.kind == ZM_MODEL_QUADCOPTER) {
+        // closed-form second derivatives of pair lp (generated, quad_derivs_gen.h) instead of the model on hyper-dual numbers;
+        // x+ = x + dt xd  =>  d2 f = dt d2 xd  (dt = 0: d2 xd itself)
+        const QuadAtoms at = quad_atoms(md, xk, uk);
+        double o[12];
+        if (md.wind_ned[0] == 0.0 && md.wind_ned[1] == 0.0 && md.wind_ned[2] == 0.0) quad_hess_pair<false>(lp, at, o);   // still air
+        else quad_hess_pair<true>(lp, at, o);
 #pragma unroll
-    for (int i = 0; i < MAXN; ++i) x[i] = Hyper{(i < n) ? xk[i] : 0.0, (i == a) ? 1.0 : 0.0, (i == b) ? 1.0 : 0.0, 0.0};
+        for (int i = 0; i < 12; ++i) h[i] = (md.dt == 0.0) ? o[i] : md.dt * o[i];
+    } else {
+        Hyper x[MAXN], u[MAXM], xn[MAXN];
 #pragma unroll
-    for (int i = 0; i < MAXM; ++i) u[i] = Hyper{(i < m) ? uk[i] : 0.0, (n + i == a) ? 1.0 : 0.0, (n + i == b) ? 1.0 : 0.0, 0.0};
-    model_step<Hyper>(md, x, u, xn);
+        for (int i = 0; i < MAXN; ++i) x[i] = Hyper{(i < n) ? xk[i] : 0.0, (i == a) ? 1.0 : 0.0, (i == b) ? 1.0 : 0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < MAXN; ++i)
-        if (i < n) o[i] = xn[i].d12;
+        for (int i = 0; i < MAXM; ++i) u[i] = Hyper{(i < m) ? uk[i] : 0.0, (n + i == a) ? 1.0 : 0.0, (n + i == b) ? 1.0 : 0.0, 0.0};
+        model_step<Hyper>(md, x, u, xn);
+#pragma unroll
+        for (int i = 0; i < MAXN; ++i) h[i] = xn[i].d12;
+    }
+    if (lp < npairs) {
+#pragma unroll
+        for (int i = 0; i < MAXN; ++i)
+            if (i < n) tile[sub][lp * n + i] = h[i];
+    }
+    wave_lds_sync();
+    double* o = H + pt * npairs * n;
+    for (int e = lp; e < npairs * n; e += LPP) o[e] = tile[sub][e];
 }
 
 // one thread per (trajectory, step) point plus one per trajectory for the terminal expansion
@@ -308,11 +442,51 @@ extern "C" int zm_linearize_dynamics_list_f64(const zm_model_t* model, const dou
     if (batch < 0 || T < 1) return zm::set_error(ZM_EINVAL, "zm_linearize_dynamics_f64: bad size");
     if ((rc = zm_check_list("zm_linearize_dynamics_list_f64", list, count, batch))) return rc;
     const long npts = (long)(list ? count : batch) * T;
-    hipLaunchKernelGGL(zm::linearize_dynamics_kernel, dim3((unsigned)((npts + 3) / 4)), dim3(64), 0, (hipStream_t)stream, md,
-                       xTraj, uTraj, (const int*)active, f, f_x, f_u, (long)batch, T, (const int*)list, (long)count);
+    constexpr int GPB = 4 * zm::LIN_WAVES;   // 16-lane groups per workgroup
+    const bool quad = md.kind == ZM_MODEL_QUADCOPTER;
+    const long ngrp = (long)(list ? count : batch) * T;
+    (void)npts;
+    const dim3 grid((unsigned)((ngrp + GPB - 1) / GPB)), block(64 * zm::LIN_WAVES);
+    if (quad)
+        hipLaunchKernelGGL((zm::linearize_dynamics_kernel<false, true>), grid, block, 0, (hipStream_t)stream, md, xTraj, uTraj,
+                           (const int*)active, f, f_x, f_u, (long)batch, T, (const int*)list, (long)count, zm::ExpandCost{});
+    else
+        hipLaunchKernelGGL((zm::linearize_dynamics_kernel<false, false>), grid, block, 0, (hipStream_t)stream, md, xTraj, uTraj,
+                           (const int*)active, f, f_x, f_u, (long)batch, T, (const int*)list, (long)count, zm::ExpandCost{});
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }
+
+// Solver-internal (ilqr_solve.hip): the per-iteration expansions of the listed trajectories in ONE launch -- [f_x | f_u] as
+// zm_linearize_dynamics_list_f64, c_x / c_u / v_x as zm_quadratize_cost_list_f64 (same expressions; tests/test_ilqr_solve_gpu.py).
+namespace zm {
+int expand_list(const zm_model_t* model, const zm_quadcost_t* cost, const double* xTraj, const double* uTraj, const int32_t* list,
+                int64_t count, const int32_t* active, double* f_x, double* f_u, double* c_x, double* c_u, double* v_x, int64_t batch,
+                int T, void* stream) {
+    if (batch == 0 || count == 0) return ZM_OK;
+    zm_model_t md;
+    int rc = zm_check_model(model, md, "expand_list");
+    if (rc) return rc;
+    if (!cost || !cost->Q || !cost->R || !cost->Qf || !xTraj || !uTraj || !list || !f_x || !f_u || !c_x || !c_u || !v_x)
+        return set_error(ZM_EINVAL, "expand_list: null pointer");
+    if (batch < 0 || T < 1 || count < 0 || count > batch) return set_error(ZM_EINVAL, "expand_list: bad size");
+    const long npts = (long)count * T;
+    constexpr int GPB = 4 * LIN_WAVES;
+    const bool quad = md.kind == ZM_MODEL_QUADCOPTER;
+    const long ngrp = (long)count * T;
+    (void)npts;
+    const dim3 grid((unsigned)((ngrp + GPB - 1) / GPB)), block(64 * LIN_WAVES);
+    const ExpandCost ec{*cost, c_x, c_u, v_x};
+    if (quad)
+        hipLaunchKernelGGL((linearize_dynamics_kernel<true, true>), grid, block, 0, (hipStream_t)stream, md, xTraj, uTraj,
+                           (const int*)active, (double*)nullptr, f_x, f_u, (long)batch, T, (const int*)list, (long)count, ec);
+    else
+        hipLaunchKernelGGL((linearize_dynamics_kernel<true, false>), grid, block, 0, (hipStream_t)stream, md, xTraj, uTraj,
+                           (const int*)active, (double*)nullptr, f_x, f_u, (long)batch, T, (const int*)list, (long)count, ec);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+}  // namespace zm
 
 extern "C" int zm_linearize_dynamics_f64(const zm_model_t* model, const double* xTraj, const double* uTraj,
                                          const int32_t* active, double* f, double* f_x, double* f_u, int64_t batch, int T,
@@ -406,7 +580,8 @@ extern "C" int zm_quadratic_dynamics_pairs_list_f64(const zm_model_t* model, con
         return zm::set_error(ZM_EUNSUPPORTED, "zm_quadratic_dynamics_pairs_list_f64: the model declares no Hessian pairs "
                                               "(zm_model_hessian_pairs); use zm_quadratic_dynamics_list_f64");
     const long npts = (list ? (long)count : (long)batch) * T;
-    hipLaunchKernelGGL(zm::quadratic_dynamics_pairs_kernel<2>, dim3((unsigned)((npts + 1) / 2)), dim3(64), 0, (hipStream_t)stream, md,
+    constexpr int PPB = 2 * zm::LIN_WAVES;   // points per workgroup
+    hipLaunchKernelGGL(zm::quadratic_dynamics_pairs_kernel<2>, dim3((unsigned)((npts + PPB - 1) / PPB)), dim3(64 * zm::LIN_WAVES), 0, (hipStream_t)stream, md,
                        xTraj, uTraj, (const int*)active, H, (long)batch, T, (const int*)list, (long)count);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;

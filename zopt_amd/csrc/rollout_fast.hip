@@ -224,7 +224,9 @@ __device__ __forceinline__ void rollout_ls_body(const FastArgs& g, const double*
 #pragma unroll
                 for (int j = 0; j < RN; ++j) s = __builtin_fma(pk[RM + i * RN + j], dx[j], s);
                 u[i] = (al * pk[i] + s) + pk[RM + RM * RN + RN + i];
-                __builtin_amdgcn_sched_barrier(0);  // one row of L_k in flight at a time
+                // one row of L_k in flight at a time (registers: three waves per SIMD) -- except in all-store mode, which runs when
+                // the chip is nearly empty and a lone wave wants its four row chains interleaved
+                if constexpr (!ALL) __builtin_amdgcn_sched_barrier(0);
             }
             J += quad_form<DIAG, RN>(Qs, x) + quad_form<DIAG, RM>(Rs, u);
             fast_step<KIND>(As, Bs, g.dt, x, u, xn);
