@@ -121,15 +121,21 @@ constexpr int ILQR_LDS_DOUBLES = 116;
 
 __device__ __forceinline__ void ilqr_lds_sync() { wave_lds_sync(); }
 
-template <int KS, int MODE, bool PREFETCH>
+// ZIN (MODE 2, the DMA kernel): the caller has contracted vf_zz = sum_i v_x[i] d2f_i/dz2 already (operands in its LDS ring) and
+// passes the tile in `zin`
+template <int KS, int MODE, bool PREFETCH, bool ZIN = false>
 __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], IlqrStepRegs<KS>& d, IlqrAddr<KS>& a,
                                           double* sm, const int g, const int c, const int ob0, const int ob1,
                                           const int ob2, const int ob3, const int oqa, double* jA, double* jV,
-                                          double* jcs, int* jpq, const int n, const int m) {
+                                          double* jcs, int* jpq, const int n, const int m, const d4 zin = d4{0.0, 0.0, 0.0, 0.0}) {
     constexpr int NP = 4 * KS;
     // MODE 2: vf_zz = sum_i v_x[i] * d2f_i/dz2, PD-projected, as extra accumulator init
     d4 pz = zero4();
-    if constexpr (MODE == 2) {
+    if constexpr (MODE == 2 && ZIN) {
+        d4 zt = zin;
+        psd_project_ns<KS + 1>(zt, a.zlive, 1e-3, jA, g, c);
+        pz = zt;
+    } else if constexpr (MODE == 2) {
         const int lane = g * 16 + c;
         double z[4] = {0.0, 0.0, 0.0, 0.0};
         // the loads of 4 slices (16 per lane) are in flight before their FMAs (unrolled, unconditional: slices i >= n
@@ -511,37 +517,45 @@ __global__ __launch_bounds__(64, 2) void ilqr_backward_t16_f64(
 // Slot image of one step (16-B chunks): f_x | f_u | c_x | c_u [| c_xx | c_ux | c_uu unless the Hessians are shared] | zeros.
 namespace zm {
 
-template <int N, int M, bool SHARED, int MODE>
+template <int N, int M, bool SHARED, int MODE, int NPAIR = 0>
 struct IlqrDmaGeom {
     static constexpr int KS = N / 4;
     static constexpr int CFX = N * N / 2, CFU = N * M / 2, CCX = N / 2, CCU = M / 2;
     static constexpr int CXX = SHARED ? 0 : N * N / 2, CUX = SHARED ? 0 : N * M / 2, CUU = SHARED ? 0 : M * M / 2;
     static constexpr int CD = (MODE == 1) ? N / 2 : 0;   // MODE 1: the affine term d of the dynamics
-    static constexpr int CT = CFX + CFU + CCX + CCU + CXX + CUX + CUU + CD;
+    static constexpr int CH = (MODE == 2) ? NPAIR * N / 2 : 0;   // MODE 2: the packed second derivatives H[pair][i] of the step
+    static constexpr int CT = CFX + CFU + CCX + CCU + CXX + CUX + CUU + CD + CH;
     static constexpr int NI = (CT + 63) / 64;
     static constexpr int SLOT = NI * 1024;
     static constexpr int OFX = 0, OFU = CFX * 16, OCX = OFU + CFU * 16, OCU = OCX + CCX * 16;
     static constexpr int OXX = OCU + CCU * 16, OUX = OXX + CXX * 16, OUU = OUX + CUX * 16;
     static constexpr int OD = OUU + CUU * 16;
+    static constexpr int OH = OD + CD * 16;
     static constexpr int OZ = CT * 16;
     static_assert(N % 4 == 0 && N >= 8 && N <= 12 && M == 4, "fast path: all K-step rows live, m = 4");
-    static_assert(MODE == 0 || (MODE == 1 && !SHARED), "sweeps without second-order dynamics");
+    static_assert(MODE == 0 || (MODE == 1 && !SHARED) || (MODE == 2 && SHARED && N == 12 && NPAIR > 0 && NPAIR <= ZM_MAX_PAIRS),
+                  "iLQR, affine LQR, or DDP with shared cost Hessians and packed second derivatives");
     static_assert(SLOT - OZ >= 16, "slot needs zero padding");
 };
 
-template <int N, int M, int D, bool SHARED, int MODE>
-__global__ __launch_bounds__(64, 3) void ilqr_backward_dma_f64(
+#ifndef ZM_DDP_DMA_WAVES
+#define ZM_DDP_DMA_WAVES 2
+#endif
+template <int N, int M, int D, bool SHARED, int MODE, int NPAIR = 0>
+__global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : 3) void ilqr_backward_dma_f64(
     const double* __restrict__ f_x, const double* __restrict__ f_u, const double* __restrict__ c_x,
     const double* __restrict__ c_u, const double* __restrict__ c_xx, const double* __restrict__ c_ux,
     const double* __restrict__ c_uu, const double* __restrict__ vf_x, const double* __restrict__ vf_xx,
     const double* __restrict__ dvec, const long svx, const long svxx, const int* __restrict__ active,
-    double* __restrict__ lout, double* __restrict__ Lout, const int T, const TrajList tl) {
-    using G = IlqrDmaGeom<N, M, SHARED, MODE>;
+    double* __restrict__ lout, double* __restrict__ Lout, const int T, const TrajList tl, const double* __restrict__ Hpk,
+    const PairTab ptab) {
+    using G = IlqrDmaGeom<N, M, SHARED, MODE, NPAIR>;
     constexpr int KS = G::KS, NI = G::NI, SLOT = G::SLOT, NP = N;
     constexpr int nn = N * N, nm = N * M, mm = M * M;
     constexpr int SMO = D * SLOT;
-    __shared__ __attribute__((aligned(16))) char lds[SMO + ILQR_LDS_DOUBLES * 8];
+    __shared__ __attribute__((aligned(16))) char lds[SMO + ILQR_LDS_DOUBLES * 8 + (MODE == 2 ? NS_LDS_DOUBLES * 8 : 0)];
     double* sm = (double*)(lds + SMO);
+    double* jA = (double*)(lds + SMO + ILQR_LDS_DOUBLES * 8);   // MODE 2: transpose buffers of the sign iteration (ns16.h)
     const int lane = threadIdx.x;
     const long traj = tl.list ? (long)tl.list[blockIdx.x] : (long)blockIdx.x;
     if (active && active[traj] == 0) return;   // whole wave leaves: this trajectory keeps its previous policy
@@ -566,6 +580,10 @@ __global__ __launch_bounds__(64, 3) void ilqr_backward_dma_f64(
                 src = (const char*)(c_x + last * N) + q * 16;   stride = N * 8;
             } else if ((q -= G::CCX) < G::CCU) {
                 src = (const char*)(c_u + last * M) + q * 16;   stride = M * 8;
+            } else if constexpr (MODE == 2) {
+                if ((q -= G::CCU) < G::CH) {
+                    src = (const char*)(Hpk + last * (long)(NPAIR * N)) + q * 16;  stride = NPAIR * N * 8;
+                }
             } else if constexpr (!SHARED) {
                 if ((q -= G::CCU) < G::CXX) {
                     src = (const char*)(c_xx + last * nn) + q * 16;  stride = nn * 8;
@@ -610,6 +628,21 @@ __global__ __launch_bounds__(64, 3) void ilqr_backward_dma_f64(
         a.pOut = a.vL ? (Lout + last * nm + g * N + c) : (lout + last * M + g);
     }
     a.sOut = vl ? M : nm;
+    // MODE 2: tile element (4r+g, c) of vf_zz is pair (min, max) of the model's table (row of the packed image) or structurally zero
+    int oH[4];
+    bool zok[4];
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * r + g;
+            const int lo = row < c ? row : c, hi = row < c ? c : row;
+            int pidx = -1;
+            for (int q = 0; q < NPAIR; ++q) pidx = (ptab.ab[q] == (unsigned char)(lo * 16 + hi)) ? q : pidx;
+            zok[r] = pidx >= 0;
+            oH[r] = G::OH + (pidx >= 0 ? pidx : 0) * (N * 8);
+            a.zlive[r] = (row == c);   // n + m = 16: every tile index is a live (state or control) index
+        }
+    }
     const bool rhs_qu = (c == NP);
     const int ob0 = rhs_qu ? (64 + NP + 0) : (0 * 16 + c);
     const int ob1 = rhs_qu ? (64 + NP + 1) : (1 * 16 + c);
@@ -673,9 +706,28 @@ __global__ __launch_bounds__(64, 3) void ilqr_backward_dma_f64(
 #pragma unroll
                 for (int s = 0; s < KS; ++s) d.dr[s] = *(const double*)(slot + G::OD + (4 * s + g) * 8);
             }
+            d4 zin = zero4();
+            if constexpr (MODE == 2) {
+                // vf_zz[4r+g][c] = sum_i v_x[i] H[pair][i], i ascending (the order of the register kernel's contraction); v_x is
+                // this wave's LDS row sm[80 ..], written by the previous step
+                double vx[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) vx[i] = sm[80 + i];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double* h = (const double*)(slot + oH[r]);
+                    double z = 0.0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) z = __builtin_fma(vx[i], h[i], z);
+                    zin[r] = zok[r] ? z : 0.0;
+                }
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // operands are in registers: the slot may be refilled
             if (j - D >= 0) dma(slot);
-            ilqr_step<KS, MODE, false>(Vxx, vxr, d, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, nullptr, nullptr, nullptr, nullptr, N, M);
+            if constexpr (MODE == 2)
+                ilqr_step<KS, MODE, false, true>(Vxx, vxr, d, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, jA, nullptr, nullptr, nullptr, N, M, zin);
+            else
+                ilqr_step<KS, MODE, false>(Vxx, vxr, d, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, nullptr, nullptr, nullptr, nullptr, N, M);
             if (--j < 0) return;
         }
     }
@@ -701,7 +753,7 @@ static int ilqr_backward_dma_dispatch(const double* f_x, const double* f_u, cons
     constexpr int DS = 3, DF = 2;
 #define ZM_LAUNCH_ILQR_DMA(NN, DD, SH)                                                                                     \
     hipLaunchKernelGGL((ilqr_backward_dma_f64<NN, 4, DD, SH, MODE>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, \
-                       vf_x, vf_xx, dvec, svx, svxx, act, l, L, T, tl)
+                       vf_x, vf_xx, dvec, svx, svxx, act, l, L, T, tl, (const double*)nullptr, PairTab{})
     if constexpr (MODE == 0) {
         if (n == 12) {
             if (sh) ZM_LAUNCH_ILQR_DMA(12, DS, true); else ZM_LAUNCH_ILQR_DMA(12, DF, false);
@@ -712,6 +764,26 @@ static int ilqr_backward_dma_dispatch(const double* f_x, const double* f_u, cons
         if (n == 12) ZM_LAUNCH_ILQR_DMA(12, DF, false); else ZM_LAUNCH_ILQR_DMA(8, DF, false);
     }
 #undef ZM_LAUNCH_ILQR_DMA
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+
+// K4-DMA: the DDP sweep with shared cost Hessians and the PACKED second derivatives (the solver's form) on the same LDS ring -- the
+// step image grows by the pairs' rows (28 x 12 doubles for the quadcopter: 4.3 KB per step), the contraction reads them from LDS.
+// ZM_EUNSUPPORTED unless (n = 12, m = 4, 28 declared pairs, 16-B aligned pointers): the caller then runs ilqr_backward_t16_f64.
+static int ddp_backward_dma_dispatch(const double* f_x, const double* f_u, const double* Hpk, const PairTab& ptab, const double* c_x,
+                                     const double* c_u, const double* c_xx, const double* c_ux, const double* c_uu, const double* vf_x,
+                                     const double* vf_xx, long svx, const int* act, int sh, double* l, double* L, int64_t batch, int T,
+                                     int n, int m, hipStream_t st, TrajList tl) {
+    static const bool off = [] {
+        const char* e = getenv("ZOPT_AMD_ILQR_PATH");
+        return e && e[0] == 'r';   // "reg": force the register kernel
+    }();
+    if (off || !sh || n != 12 || m != 4 || ptab.n != 28 || !Hpk) return ZM_EUNSUPPORTED;
+    if (((uintptr_t)f_x | (uintptr_t)f_u | (uintptr_t)c_x | (uintptr_t)c_u | (uintptr_t)Hpk) & 15) return ZM_EUNSUPPORTED;
+    const dim3 grid((unsigned)(tl.list ? tl.count : batch)), block(64);
+    hipLaunchKernelGGL((ilqr_backward_dma_f64<12, 4, 2, true, 2, 28>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
+                       vf_xx, (const double*)nullptr, svx, 0L, act, l, L, T, tl, Hpk, ptab);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }
@@ -854,6 +926,11 @@ extern "C" int zm_ddp_backward_pairs_list_f64(const zm_model_t* model, const dou
     if (pt.n < 1)
         return zm::set_error(ZM_EUNSUPPORTED, "zm_ddp_backward_pairs_list_f64: the model declares no Hessian pairs");
     const zm::TrajList tl{(const int*)list, (long)count};
+    {   // the LDS-ring kernel where it applies (quadcopter shapes, shared cost Hessians); the register kernel otherwise
+        const int rd = zm::ddp_backward_dma_dispatch(f_x, f_u, H, pt, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, (long)n, (const int*)active,
+                                                     shared_hessian ? 1 : 0, l, L, batch, T, n, m, (hipStream_t)stream, tl);
+        if (rd != ZM_EUNSUPPORTED) return rd;
+    }
     zm::DdpTensors z{nullptr, nullptr, nullptr, H, pt};
     return zm::launch_ilqr<2>(f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, (long)n, (long)n * n, (const int*)active,
                               shared_hessian ? 1 : 0, l, L, batch, T, n, m, (hipStream_t)stream, z,
