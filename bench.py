@@ -471,12 +471,12 @@ def run_rank(args):
             res["stub"] = True
             res["roofline"]["kernel"] = "stub (CPU tensor op): harness rehearsal, not a measurement"
         if (n, m) == (12, 4) and not work.stub:
-            # Informational: the fp64 matrix pipe is the resource this kernel actually saturates.  Per horizon step the wave
-            # issues 9 v_mfma_f64_16x16x4 (2048 flop) + 3 v_mfma_f64_4x4x4_4b (512 flop); the sustained fp64 MFMA rate of the
-            # chip, measured at steady state (profiles/r01_ubench_mfma_f64_steady.txt), is 47.2 TFLOP/s (nominal 78.6).
+            # Informational: what the kernel issues on the fp64 matrix pipe.  Per horizon step a wave issues 9 v_mfma_f64_16x16x4
+            # (2048 flop) + 3 v_mfma_f64_4x4x4_4b (512 flop).  The pipe's peak is the nominal 78.6 TFLOP/s: the chip holds 2.35-2.39 GHz
+            # under pure fp64 MFMA load and issues one 16x16x4 per 64 cycles and SIMD (profiles/r02_ubench_clock_f64.txt; round 1's
+            # "47.2 TFLOP/s sustained" was an artifact of its microbenchmark).  This kernel is bound by the memory system, not by this pipe.
             issued = (9 * 2048 + 3 * 512) * steps_per_launch / (kern_ms * 1e-3) / 1e12
-            res["fp64_matrix_pipe"] = {"issued_mfma_tflops": issued, "sustained_peak_tflops": 47.2, "nominal_peak_tflops": 78.6,
-                                       "frac_of_sustained": issued / 47.2}
+            res["fp64_matrix_pipe"] = {"issued_mfma_tflops": issued, "peak_tflops": 78.6, "frac": issued / 78.6}
         if gather_ms is not None:
             nbytes = world * batch * T * m * n * 8
             res["allgather"] = {"ms": gather_ms, "bytes_per_rank": nbytes, "GBps_per_rank": nbytes / (gather_ms * 1e-3) / 1e9}

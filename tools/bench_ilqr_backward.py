@@ -90,6 +90,20 @@ def main():
                       "horizon_steps_per_s": b * T / t, "bytes_per_step": bs, "algorithmic_GBps": b * T * bs / t / 1e9,
                       "hbm_frac": b * T * bs / t / 8e12}))
     del f_xx, f_ux, f_uu
+    # K4 as the fused DDP driver runs it: packed second derivatives of the quadcopter's 28 declared pairs, shared cost Hessians
+    # (zm_ddp_backward_pairs_list_f64 -> the LDS-ring kernel ilqr_backward_dma_f64<MODE 2>)
+    from zopt_amd import models
+    md = models.QuadcopterEuler(0.1).c_struct()
+    Hp = rn(b, T, 28, n) * 0.05
+    t = timeit(lambda: _lib.check(lib.zm_ddp_backward_pairs_list_f64(
+        ctypes.addressof(md), f_x.data_ptr(), f_u.data_ptr(), Hp.data_ptr(), c_x.data_ptr(), c_u.data_ptr(), sh[0].data_ptr(),
+        sh[1].data_ptr(), sh[2].data_ptr(), v_x.data_ptr(), sh[3].data_ptr(), None, 0, None, 1, l.data_ptr(), L.data_ptr(), b, T, st),
+        "ddp packed"))
+    bs = 8 * (n * n + n * m + n + m + 28 * n + m + m * n)
+    print(json.dumps({"kernel": "ilqr_backward_dma_f64<MODE 2> (DDP, packed pairs, shared Hessians)", "batch": b, "T": T, "us": t * 1e6,
+                      "horizon_steps_per_s": b * T / t, "bytes_per_step": bs, "algorithmic_GBps": b * T * bs / t / 1e9,
+                      "hbm_frac": b * T * bs / t / 8e12}))
+    del Hp
     # K2: bilinearAffineLqr
     for (n2, m2) in ((12, 4), (8, 4)):
         A2 = rn(b, T, n2, n2) * (0.9 / n2 ** 0.5)

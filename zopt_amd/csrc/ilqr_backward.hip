@@ -541,8 +541,11 @@ struct IlqrDmaGeom {
 #ifndef ZM_DDP_DMA_WAVES
 #define ZM_DDP_DMA_WAVES 2
 #endif
+#ifndef ZM_ILQR_DMA_WAVES
+#define ZM_ILQR_DMA_WAVES 3
+#endif
 template <int N, int M, int D, bool SHARED, int MODE, int NPAIR = 0>
-__global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : 3) void ilqr_backward_dma_f64(
+__global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVES) void ilqr_backward_dma_f64(
     const double* __restrict__ f_x, const double* __restrict__ f_u, const double* __restrict__ c_x,
     const double* __restrict__ c_u, const double* __restrict__ c_xx, const double* __restrict__ c_ux,
     const double* __restrict__ c_uu, const double* __restrict__ vf_x, const double* __restrict__ vf_xx,
