@@ -203,6 +203,13 @@ __device__ __forceinline__ void rollout_ls_body(const FastArgs& g, const double*
             }
         }
         double J = 0.0;
+        double qd[(ALL && DIAG) ? RN : 1], rd[(ALL && DIAG) ? RM : 1];
+        if constexpr (ALL && DIAG) {
+#pragma unroll
+            for (int j = 0; j < RN; ++j) qd[j] = Qs[j * RN + j];
+#pragma unroll
+            for (int j = 0; j < RM; ++j) rd[j] = Rs[j * RM + j];
+        }
         for (int k = 0; k < T; ++k) {
             const int cur = k & 1;
             const bool more = (k + 1 < T);
@@ -213,7 +220,17 @@ __device__ __forceinline__ void rollout_ls_body(const FastArgs& g, const double*
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const double* pk = pol[cur][grp];
+            const double* pks = pol[cur][grp];
+            // All-store mode runs as a lone wave per SIMD with registers to spare: the step's 68 policy values are fetched from LDS
+            // in one batch and waited for once -- read where they are used, each of ~40 waits exposed part of an LDS round trip to
+            // the dependency chain.  (Same values, same arithmetic.)
+            double pkr[ALL ? PSZ : 1];
+            if constexpr (ALL) {
+#pragma unroll
+                for (int e = 0; e < PSZ; ++e) pkr[e] = pks[e];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            const double* pk = ALL ? pkr : pks;
             // u = (alpha * l_k + L_k (x - xPrev_k)) + uPrev_k            (pytrees.py:220, ilqrUtils.py:59-60)
             double dx[RN];
 #pragma unroll
@@ -228,7 +245,16 @@ __device__ __forceinline__ void rollout_ls_body(const FastArgs& g, const double*
                 // the chip is nearly empty and a lone wave wants its four row chains interleaved
                 if constexpr (!ALL) __builtin_amdgcn_sched_barrier(0);
             }
-            J += quad_form<DIAG, RN>(Qs, x) + quad_form<DIAG, RM>(Rs, u);
+            if constexpr (ALL && DIAG) {   // the diagonal weights from registers (loaded before the loop); quad_form's arithmetic
+                double jx = 0.0, ju = 0.0;
+#pragma unroll
+                for (int j = 0; j < RN; ++j) jx = __builtin_fma(x[j] * qd[j], x[j], jx);
+#pragma unroll
+                for (int j = 0; j < RM; ++j) ju = __builtin_fma(u[j] * rd[j], u[j], ju);
+                J += jx + ju;
+            } else {
+                J += quad_form<DIAG, RN>(Qs, x) + quad_form<DIAG, RM>(Rs, u);
+            }
             fast_step<KIND>(As, Bs, g.dt, x, u, xn);
 #pragma unroll
             for (int i = 0; i < RN; ++i) x[i] = xn[i];
