@@ -169,14 +169,20 @@ def main():
         fh.write("// what the closed forms read: the state, the thrust, the NED wind, sin / cos of phi (6), theta (7), psi (8), 1 / cos(theta)\n")
         fh.write("struct QuadAtoms {\n    double x[12], u0, w[3], s6, c6, s7, c7, s8, c8, ic7;\n};\n\n")
         stats = {}
-        for fn, which, doc in (("quad_jac_column", 0, "o[i] = d xd_i / d z_j, z = [x ; u], column j"),
-                               ("quad_hess_pair", 1, "o[i] = d2 xd_i / d z_a d z_b for declared pair j (models.h model_pair_table)")):
+        def two_pairs(hes):   # case j: pairs 2j (o[0..11]) and 2j+1 (o[12..23])
+            return {j: [(12 * (p & 1) + i, e) for p in (2 * j, 2 * j + 1) if p in hes for i, e in hes[p]] for j in range((len(PAIRS) + 1) // 2)}
+
+        for fn, table, nout, doc in (
+                ("quad_jac_column", lambda w: d[w][0], 12, "o[i] = d xd_i / d z_j, z = [x ; u], column j"),
+                ("quad_hess_pair", lambda w: d[w][1], 12, "o[i] = d2 xd_i / d z_a d z_b for declared pair j (models.h model_pair_table)"),
+                ("quad_hess_pair2", lambda w: two_pairs(d[w][1]), 24,
+                 "two declared pairs per case: o[i] = d2 xd_i for pair 2j, o[12 + i] for pair 2j+1 (14 cases: a 16-lane group per point)")):
             fh.write(f"// {doc}; entries not assigned are zero.  Temporaries shared by several cases are computed before the switch.\n")
-            fh.write(f"template <bool WIND>\nZM_HD void {fn}(const int j, const QuadAtoms& a, double (&o)[12]) {{\n")
-            fh.write("    for (int i = 0; i < 12; ++i) o[i] = 0.0;\n    if constexpr (WIND) {\n")
-            stats[(fn, True)] = emit_body(fh, d[True][which], pr, "        ")
+            fh.write(f"template <bool WIND>\nZM_HD void {fn}(const int j, const QuadAtoms& a, double (&o)[{nout}]) {{\n")
+            fh.write(f"    for (int i = 0; i < {nout}; ++i) o[i] = 0.0;\n    if constexpr (WIND) {{\n")
+            stats[(fn, True)] = emit_body(fh, table(True), pr, "        ")
             fh.write("    } else {\n")
-            stats[(fn, False)] = emit_body(fh, d[False][which], pr, "        ")
+            stats[(fn, False)] = emit_body(fh, table(False), pr, "        ")
             fh.write("    }\n}\n\n")
         fh.write("}  // namespace zm\n")
     for k, v in stats.items():

@@ -317,6 +317,42 @@ __global__ __launch_bounds__(64 * LIN_WAVES) void quadratic_dynamics_pairs_kerne
     for (int e = lp; e < npairs * n; e += LPP) o[e] = tile[sub][e];
 }
 
+// The quadcopter's packed second derivatives with 16 lanes per point (4 points per wave instead of 2): lane j < 14 evaluates the
+// closed forms of pairs 2j and 2j+1 (quad_hess_pair2), the 28 x 12 image of the point is gathered in LDS and leaves as whole lines.
+// Halves the instructions per point of quadratic_dynamics_pairs_kernel (whose 32-lane groups leave every second SIMD lane group idle
+// through the shared part).
+__global__ __launch_bounds__(64 * LIN_WAVES) void quad_hessian_pairs16_kernel(const zm_model_t md, const double* __restrict__ xTraj,
+                                                                              const double* __restrict__ uTraj,
+                                                                              const int* __restrict__ active, double* __restrict__ H,
+                                                                              const long batch, const int T,
+                                                                              const int* __restrict__ list, const long count) {
+    constexpr int NPR = 28, ROW = NPR * 12;
+    __shared__ double tile[4 * LIN_WAVES][ROW];
+    const int j = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const long nslot = list ? count : batch;
+    const long sp = (long)blockIdx.x * (4 * LIN_WAVES) + q;   // slot * T + k
+    if (sp >= nslot * T) return;
+    const long slot = sp / T;
+    const int k = (int)(sp - slot * T);
+    const long traj = list ? (long)list[slot] : slot;
+    const long pt = traj * T + k;
+    const double* xk = xTraj + (traj * (T + 1) + k) * 12;
+    const double* uk = uTraj + pt * 4;
+    const QuadAtoms at = quad_atoms(md, xk, uk);
+    if (active && active[traj] == 0) return;
+    double o[24];
+    if (md.wind_ned[0] == 0.0 && md.wind_ned[1] == 0.0 && md.wind_ned[2] == 0.0) quad_hess_pair2<false>(j, at, o);   // still air
+    else quad_hess_pair2<true>(j, at, o);
+    if (j < NPR / 2) {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) tile[q][j * 24 + i] = (md.dt == 0.0) ? o[i] : md.dt * o[i];   // x+ = x + dt xd  =>  d2 f = dt d2 xd
+    }
+    wave_lds_sync();
+    double* out = H + pt * ROW;
+#pragma unroll
+    for (int e = 0; e < ROW / 16; ++e) out[j + 16 * e] = tile[q][j + 16 * e];
+}
+
 // one thread per (trajectory, step) point plus one per trajectory for the terminal expansion
 __global__ __launch_bounds__(256) void quadratize_cost_kernel(const zm_quadcost_t cs, const int n, const int m,
                                                               const double* __restrict__ xTraj,
@@ -580,6 +616,13 @@ extern "C" int zm_quadratic_dynamics_pairs_list_f64(const zm_model_t* model, con
         return zm::set_error(ZM_EUNSUPPORTED, "zm_quadratic_dynamics_pairs_list_f64: the model declares no Hessian pairs "
                                               "(zm_model_hessian_pairs); use zm_quadratic_dynamics_list_f64");
     const long npts = (list ? (long)count : (long)batch) * T;
+    if (md.kind == ZM_MODEL_QUADCOPTER) {
+        constexpr int PPB16 = 4 * zm::LIN_WAVES;
+        hipLaunchKernelGGL(zm::quad_hessian_pairs16_kernel, dim3((unsigned)((npts + PPB16 - 1) / PPB16)), dim3(64 * zm::LIN_WAVES), 0,
+                           (hipStream_t)stream, md, xTraj, uTraj, (const int*)active, H, (long)batch, T, (const int*)list, (long)count);
+        ZM_HIP_CHECK(hipGetLastError());
+        return ZM_OK;
+    }
     constexpr int PPB = 2 * zm::LIN_WAVES;   // points per workgroup
     hipLaunchKernelGGL(zm::quadratic_dynamics_pairs_kernel<2>, dim3((unsigned)((npts + PPB - 1) / PPB)), dim3(64 * zm::LIN_WAVES), 0, (hipStream_t)stream, md,
                        xTraj, uTraj, (const int*)active, H, (long)batch, T, (const int*)list, (long)count);
