@@ -31,14 +31,20 @@ print("CHILD-OK", int(np.sum(conv)))
 
 @pytest.mark.parametrize("solver", ["ilqr", "ddp"])
 def test_solve_is_bit_identical_for_every_tail_threshold(solver, tmp_path):
+    """... and whether or not the four-lanes-per-rollout kernels (rollout_quad.hip: the all-store search of few trajectories, the
+    re-roll of the winners as its own launch) take part (ZOPT_AMD_ROLLOUT_QUAD=0: everything in rollout_ls_fast_kernel)."""
     res = {}
-    for thr in ("0", "1000000", "40"):      # never / from the first iteration / switches when 40 of the 96 are left
-        out = tmp_path / f"{solver}_{thr}.npz"
-        p = subprocess.run([sys.executable, "-c", CHILD, str(out), solver], env=dict(os.environ, ZOPT_AMD_ILQR_TAIL=thr),
-                           capture_output=True, text=True, timeout=600, cwd=ROOT)
+    # never / from the first iteration / switches when 40 of the 96 are left; the same without the quad kernels
+    cases = [("0", "1"), ("1000000", "1"), ("40", "1"), ("0", "0"), ("1000000", "0"), ("40", "0")]
+    for thr, quad in cases:
+        out = tmp_path / f"{solver}_{thr}_{quad}.npz"
+        p = subprocess.run([sys.executable, "-c", CHILD, str(out), solver],
+                           env=dict(os.environ, ZOPT_AMD_ILQR_TAIL=thr, ZOPT_AMD_ROLLOUT_QUAD=quad), capture_output=True, text=True,
+                           timeout=600, cwd=ROOT)
         assert p.returncode == 0 and "CHILD-OK" in p.stdout, (p.stdout[-300:], p.stderr[-1500:])
-        res[thr] = dict(np.load(out))
-    assert res["0"]["c"].sum() > 48                      # the problem set mostly converges (a real solve, not a no-op)
-    for thr in ("1000000", "40"):
+        res[(thr, quad)] = dict(np.load(out))
+    ref = res[("0", "0")]
+    assert ref["c"].sum() > 48                           # the problem set mostly converges (a real solve, not a no-op)
+    for case in cases[:-3] + cases[-2:]:
         for k in ("x", "u", "L", "J", "c"):
-            assert np.array_equal(res["0"][k], res[thr][k], equal_nan=True), (solver, thr, k)
+            assert np.array_equal(ref[k], res[case][k], equal_nan=True), (solver, case, k)

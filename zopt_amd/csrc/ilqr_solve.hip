@@ -233,7 +233,7 @@ extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* c
                                  ws + w.scratch, widx);
         } else {
             rc = zm_rollout_linesearch_list_f64(model, cost, x0, ws + w.l, L, xTraj, uTraj, ws + w.alphas, 16, list, count, active,
-                                                ws + w.xT2, ws + w.uT2, ws + w.Jn, nullptr, batch, T, st);
+                                                ws + w.xT2, ws + w.uT2, ws + w.Jn, widx, batch, T, st);
             if (rc) return rc;
             rc = zm_ilqr_accept_f64(list, count, J, ws + w.Jn, xTraj, ws + w.xT2, uTraj, ws + w.uT2, converged, active, tol, batch, T,
                                     n, m, st);

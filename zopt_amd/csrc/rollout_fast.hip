@@ -12,7 +12,10 @@
 //    slowest wave's 2 x T dependent steps): EVERY lane stores its rollout into a scratch row [slot][step size], no second pass at
 //    all -- the accept step copies the winner's row.  16x the stores, half the chain.
 #include "models.h"
+#include "quad_step.h"
 #include "zm_common.h"
+
+#include <cstdlib>
 
 namespace zm {
 
@@ -43,6 +46,7 @@ struct FastArgs {
     int T;
     int n_alpha;       // 16, or 1: every lane of a trajectory's group rolls the same step size (lane 0 stores; no second pass)
     double* scratch;   // all-store mode (else nullptr): per slot (T+1) blocks of ALLSTORE_BLOCK doubles, see allstore_offset()
+    int no_pass2;      // the winners are re-rolled by rollout_quad_reroll_kernel afterwards (needs idx)
 };
 
 // All-store scratch layout: the 16 lanes of a trajectory write NEIGHBOURING 16-byte pieces, so that one store instruction of a group
@@ -56,38 +60,11 @@ template <int KIND>
 __device__ __forceinline__ void fast_step(const double* As, const double* Bs, const double dt,
                                           const double (&x)[RN], const double (&u)[RM], double (&xn)[RN]) {
     if constexpr (KIND == ZM_MODEL_QUADCOPTER) {
-        // quad_inertial_dynamics<double> with sincos (tan = sin/cos): models.h / quadcopter.py:23-144
-        constexpr double g = 9.807, mass = 2.5;
         double sphi, cphi, sth, cth, spsi, cpsi;
         zm_sincos(x[6], &sphi, &cphi);
         zm_sincos(x[7], &sth, &cth);
         zm_sincos(x[8], &spsi, &cpsi);
-        const double icth = 1.0 / cth;   // one division: tan(theta) = sin * (1 / cos), and the two quotients of the psi-dot row
-        const double tth = sth * icth;
-        const double fa0 = -0.2 * x[0] + -0.05 * (x[0] * x[0]);
-        const double fa1 = -0.2 * x[1] + -0.05 * (x[1] * x[1]);
-        const double fa2 = -0.3 * x[2] + -0.1 * (x[2] * x[2]);
-        const double ft0 = fa0 + (mass * g) * (-sth);
-        const double ft1 = fa1 + (mass * g) * (sphi * cth);
-        const double ft2 = ((mass * (-u[0])) + fa2) + (mass * g) * (cphi * cth);
-        const double c0 = x[4] * x[2] - x[5] * x[1];
-        const double c1 = x[5] * x[0] - x[3] * x[2];
-        const double c2 = x[3] * x[1] - x[4] * x[0];
-        double xd[RN];
-        xd[0] = (1.0 / mass) * (ft0 - c0);
-        xd[1] = (1.0 / mass) * (ft1 - c1);
-        xd[2] = (1.0 / mass) * (ft2 - c2);
-        xd[3] = u[1] + -0.1 * x[3];
-        xd[4] = u[2] + -0.1 * x[4];
-        xd[5] = u[3] + -0.05 * x[5];
-        xd[6] = (x[3] + (sphi * tth) * x[4]) + (cphi * tth) * x[5];
-        xd[7] = cphi * x[4] - sphi * x[5];
-        xd[8] = (sphi * icth) * x[4] + (cphi * icth) * x[5];
-        xd[9] = ((cth * cpsi) * x[0] + (sphi * sth * cpsi - cphi * spsi) * x[1]) + (cphi * sth * cpsi - sphi * spsi) * x[2];
-        xd[10] = ((cth * spsi) * x[0] + (sphi * sth * spsi + cphi * cpsi) * x[1]) + (cphi * sth * spsi - sphi * cpsi) * x[2];
-        xd[11] = ((-sth) * x[0] + (sphi * cth) * x[1]) + (cphi * cth) * x[2];
-#pragma unroll
-        for (int i = 0; i < RN; ++i) xn[i] = x[i] + dt * xd[i];
+        quad_euler_step_trig(x, u, dt, sphi, cphi, sth, cth, spsi, cpsi, xn);
     } else {
 #pragma unroll
         for (int i = 0; i < RN; ++i) {
@@ -310,7 +287,7 @@ __device__ __forceinline__ void rollout_ls_body(const FastArgs& g, const double*
             if (g.J) g.J[t] = Jbest;
             if (g.idx) g.idx[t] = best;
         }
-        const bool need2 = live && best != 0 && !ALL;
+        const bool need2 = live && best != 0 && !ALL && !g.no_pass2;
         if (__ballot(need2) == 0ull) break;
         al = g.alphas[best];
         store = need2 && a == 0;
@@ -372,15 +349,45 @@ static int launch_fast(const FastArgs& g, const bool diag_only, hipStream_t st) 
     return ZM_OK;
 }
 
+// rollout_quad.hip: four lanes per rollout (quadcopter, still air, diagonal weights)
+struct QuadArgs {
+    double dt;
+    const double *Q, *R, *Qf, *x0, *l, *L, *xPrev, *uPrev, *alphas;
+    const int *active, *list;
+    long count;
+    double *xTraj, *uTraj, *J;
+    int* idx;
+    long batch;
+    int T;
+    double* scratch;
+};
+int rollout_quad_all(const QuadArgs& g, hipStream_t st);
+int rollout_quad_reroll(const QuadArgs& g, hipStream_t st);
+
 // Fast path dispatch: (n, m) = (12, 4), 16 step sizes.
 int rollout_fast_dispatch(const zm_model_t& md, const double* Q, const double* R, const double* Qf, int diagonal,
                           const double* x0, const double* l, const double* L, const double* xPrev, const double* uPrev,
                           const double* alphas, int n_alpha, const int* active, const int* list, int64_t count, double* xTraj,
                           double* uTraj, double* J, int* idx, int64_t batch, int T, hipStream_t st, double* scratch) {
     FastArgs g{md.A, md.B, md.dt, Q, R, Qf, x0, l, L, xPrev, uPrev, alphas, active, list, (long)count, xTraj, uTraj, J, idx,
-               (long)batch, T, n_alpha, scratch};
-    if (md.kind == ZM_MODEL_QUADCOPTER) return launch_fast<ZM_MODEL_QUADCOPTER>(g, diagonal == 1, st);
-    return launch_fast<ZM_MODEL_LINEAR>(g, diagonal == 1, st);
+               (long)batch, T, n_alpha, scratch, 0};
+    // ZOPT_AMD_ROLLOUT_QUAD=0: everything in rollout_ls_fast_kernel (A/B; same results)
+    static const bool quad_on = [] {
+        const char* e = getenv("ZOPT_AMD_ROLLOUT_QUAD");
+        return !(e && e[0] == '0');
+    }();
+    const bool quad = quad_on && md.kind == ZM_MODEL_QUADCOPTER && diagonal == 1 && n_alpha == 16 && J && idx;
+    const QuadArgs qa{md.dt, Q, R, Qf, x0, l, L, xPrev, uPrev, alphas, active, list, (long)count, xTraj, uTraj, J, idx, (long)batch, T, scratch};
+    // all-store line search with at most ~0.6 waves per SIMD: one trajectory per wave, 4 lanes per step size (78 against 104 us per
+    // launch).  With more trajectories its 4x as many waves no longer run alone and the 4-trajectories-per-wave kernel is faster
+    // (measured: 1131 trajectories 145 against ~125 us).
+    if (quad && scratch && count <= 640) return rollout_quad_all(qa, st);
+    if (quad && !scratch) g.no_pass2 = 1;                              // two-pass line search: the second pass as its own, densely packed launch
+    int rc;
+    if (md.kind == ZM_MODEL_QUADCOPTER) rc = launch_fast<ZM_MODEL_QUADCOPTER>(g, diagonal == 1, st);
+    else rc = launch_fast<ZM_MODEL_LINEAR>(g, diagonal == 1, st);
+    if (rc || !quad || scratch) return rc;
+    return rollout_quad_reroll(qa, st);
 }
 
 }  // namespace zm
