@@ -18,7 +18,7 @@ sys.path.insert(0, %r)
 from zopt_amd import ilqrUtils, models
 ddp = sys.argv[2] == "ddp"
 rng = np.random.default_rng(11)
-B, N = 96, 30
+B, N = 96, int(sys.argv[3]) if len(sys.argv) > 3 else 30
 x0 = np.zeros((B, 12)); x0[:, 9:12] = rng.uniform(-10, 10, (B, 3))
 ug = np.tile(models.QuadcopterEuler.uTrim, (B, N, 1))
 cost = models.QuadraticCost(np.eye(12), (0.2 if ddp else 1.0) * np.eye(4), 10 * np.eye(12))
@@ -48,3 +48,21 @@ def test_solve_is_bit_identical_for_every_tail_threshold(solver, tmp_path):
     for case in cases[:-3] + cases[-2:]:
         for k in ("x", "u", "L", "J", "c"):
             assert np.array_equal(ref[k], res[case][k], equal_nan=True), (solver, case, k)
+
+
+@pytest.mark.parametrize("N", [1, 2, 7])
+def test_short_and_odd_horizons_agree_across_line_search_forms(N, tmp_path):
+    """The four-lane kernels walk the horizon two steps per loop iteration (ping-pong operand registers) with a tail step for odd T:
+    horizons 1, 2 and 7, all-store from the start and never, with and without the quad kernels -- the same bits."""
+    res = {}
+    cases = [("0", "0"), ("1000000", "1"), ("0", "1"), ("1000000", "0")]
+    for thr, quad in cases:
+        out = tmp_path / f"h{N}_{thr}_{quad}.npz"
+        p = subprocess.run([sys.executable, "-c", CHILD, str(out), "ilqr", str(N)],
+                           env=dict(os.environ, ZOPT_AMD_ILQR_TAIL=thr, ZOPT_AMD_ROLLOUT_QUAD=quad), capture_output=True, text=True,
+                           timeout=600, cwd=ROOT)
+        assert p.returncode == 0 and "CHILD-OK" in p.stdout, (p.stdout[-300:], p.stderr[-1500:])
+        res[(thr, quad)] = dict(np.load(out))
+    for case in cases[1:]:
+        for k in ("x", "u", "L", "J", "c"):
+            assert np.array_equal(res[cases[0]][k], res[case][k], equal_nan=True), (N, case, k)

@@ -228,3 +228,43 @@ def test_diagonal_weight_kernels_agree(mods, kind):
                                  zo.Trajectory(xPrev[b], uPrev[b]))
         assert abs(J[b] - rJ) <= 1e-10 * abs(rJ)
         assert _rel(traj.xTraj[b], rt.xTraj) <= 1e-9 and _rel(traj.uTraj[b], rt.uTraj) <= 1e-9
+
+
+@pytest.mark.parametrize("N", [1, 2, 9, 30])
+def test_reroll_as_its_own_launch_matches_the_second_pass(mods, N):
+    """zm_rollout_linesearch_list_f64 with an alpha_idx buffer re-rolls the winners in rollout_quad_reroll_kernel (four lanes per
+    rollout, 16 trajectories per wave); without one the second pass runs inside the line-search kernel.  Same bits, same winners,
+    also under a list with a mask and for horizons that exercise the two-steps-per-iteration loop's tail."""
+    import ctypes
+    import torch
+    from zopt_amd import _lib
+    ilqr, models, pt = mods
+    rng = np.random.default_rng(100 + N)
+    batch = 37
+    x0, l, L, xPrev, uPrev = _quad_problem(rng, batch, N)
+    l *= 60.0
+    cost = models.QuadraticCost(np.diag(rng.uniform(0.5, 2.0, 12)), np.diag(rng.uniform(0.5, 2.0, 4)), np.diag(rng.uniform(5.0, 20.0, 12)))
+    md, cs = models.QuadcopterEuler(0.1).c_struct(), cost.c_struct()
+    dev = [torch.as_tensor(np.ascontiguousarray(X), device="cuda") for X in (x0, l, L, xPrev, uPrev)]
+    al = torch.as_tensor(0.5 ** np.arange(16), device="cuda")
+    lst = torch.as_tensor(np.array([3, 0, 36, 17, 18, 19, 20, 5, 6, 7, 30, 31, 8, 9, 10, 11, 12, 1, 2], dtype=np.int32), device="cuda")
+    act = torch.ones(batch, dtype=torch.int32, device="cuda")
+    act[17] = 0
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = []
+    for with_idx in (False, True):
+        xT = torch.full((batch, N + 1, 12), -7.0, dtype=torch.float64, device="cuda")
+        uT = torch.full((batch, N, 4), -7.0, dtype=torch.float64, device="cuda")
+        J = torch.full((batch,), -7.0, dtype=torch.float64, device="cuda")
+        idx = torch.full((batch,), -1, dtype=torch.int32, device="cuda")
+        _lib.check(_lib.lib().zm_rollout_linesearch_list_f64(
+            ctypes.addressof(md), ctypes.addressof(cs), *[t.data_ptr() for t in dev], al.data_ptr(), 16, lst.data_ptr(), lst.numel(),
+            act.data_ptr(), xT.data_ptr(), uT.data_ptr(), J.data_ptr(), idx.data_ptr() if with_idx else None, batch, N, st), "rollout")
+        torch.cuda.synchronize()
+        out.append((xT.cpu().numpy(), uT.cpu().numpy(), J.cpu().numpy(), idx.cpu().numpy()))
+    (x1, u1, J1, _), (x2, u2, J2, i2) = out
+    assert np.array_equal(x1, x2) and np.array_equal(u1, u2) and np.array_equal(J1, J2)
+    listed = sorted(set(lst.cpu().numpy().tolist()) - {17})
+    assert np.all(x2[17] == -7.0) and np.all(i2[listed] >= 0) and len(set(i2[listed].tolist())) > 1   # several winners, not only alpha_0
+    untouched = sorted(set(range(batch)) - set(lst.cpu().numpy().tolist()))
+    assert np.all(x2[untouched] == -7.0) and np.all(J2[untouched] == -7.0)

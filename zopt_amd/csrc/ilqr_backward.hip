@@ -122,8 +122,8 @@ constexpr int ILQR_LDS_DOUBLES = 116;
 __device__ __forceinline__ void ilqr_lds_sync() { wave_lds_sync(); }
 
 // ZIN (MODE 2, the DMA kernel): the caller has contracted vf_zz = sum_i v_x[i] d2f_i/dz2 already (operands in its LDS ring) and
-// passes the tile in `zin`
-template <int KS, int MODE, bool PREFETCH, bool ZIN = false>
+// passes the tile in `zin` (1), or has PD-projected it as well (2)
+template <int KS, int MODE, bool PREFETCH, int ZIN = 0>
 __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], IlqrStepRegs<KS>& d, IlqrAddr<KS>& a,
                                           double* sm, const int g, const int c, const int ob0, const int ob1,
                                           const int ob2, const int ob3, const int oqa, double* jA, double* jV,
@@ -131,7 +131,9 @@ __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], 
     constexpr int NP = 4 * KS;
     // MODE 2: vf_zz = sum_i v_x[i] * d2f_i/dz2, PD-projected, as extra accumulator init
     d4 pz = zero4();
-    if constexpr (MODE == 2 && ZIN) {
+    if constexpr (MODE == 2 && ZIN == 2) {
+        pz = zin;                                    // projected by the caller
+    } else if constexpr (MODE == 2 && ZIN == 1) {
         d4 zt = zin;
         psd_project_ns<KS + 1>(zt, a.zlive, 1e-3, jA, g, c);
         pz = zt;
@@ -556,9 +558,16 @@ __global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVE
     constexpr int KS = G::KS, NI = G::NI, SLOT = G::SLOT, NP = N;
     constexpr int nn = N * N, nm = N * M, mm = M * M;
     constexpr int SMO = D * SLOT;
-    __shared__ __attribute__((aligned(16))) char lds[SMO + ILQR_LDS_DOUBLES * 8 + (MODE == 2 ? NS_LDS_DOUBLES * 8 : 0)];
+    // MODE 2 with three waves per SIMD (ZM_DDP_DMA_WAVES = 3) keeps state in LDS while the projection runs: X of the sign iteration
+    // (256 doubles), the value function V, v (6 doubles per lane) and the shared cost Hessian (4 per lane)
+    constexpr bool DIET = (MODE == 2) && (ZM_DDP_DMA_WAVES >= 3);
+    constexpr int XST = DIET ? 256 : 0, VST = DIET ? 64 * 2 * KS : 0, CST = DIET ? 64 * (KS + 1) : 0;
+    __shared__ __attribute__((aligned(16))) char lds[SMO + ILQR_LDS_DOUBLES * 8 + (MODE == 2 ? NS_LDS_DOUBLES * 8 : 0) + (XST + VST + CST) * 8];
     double* sm = (double*)(lds + SMO);
     double* jA = (double*)(lds + SMO + ILQR_LDS_DOUBLES * 8);   // MODE 2: transpose buffers of the sign iteration (ns16.h)
+    double* xst = jA + NS_LDS_DOUBLES;
+    double* vst = xst + XST;
+    double* cst = vst + VST;
     const int lane = threadIdx.x;
     const long traj = tl.list ? (long)tl.list[blockIdx.x] : (long)blockIdx.x;
     if (active && active[traj] == 0) return;   // whole wave leaves: this trajectory keeps its previous policy
@@ -680,6 +689,11 @@ __global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVE
         }
         if (g == 0) sm[80 + c] = cA ? vx[c] : 0.0;
     }
+    if constexpr (DIET) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) cst[s * 64 + lane] = Csh[s];
+        cst[KS * 64 + lane] = Cush;
+    }
     ilqr_lds_sync();
 
 #pragma unroll
@@ -692,10 +706,14 @@ __global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVE
             char* slot = lds + si * SLOT;
             wait_for_step<NI, D>(j);
             IlqrStepRegs<KS> d;
+            if constexpr (!DIET) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) d.F[s] = *(const double*)(slot + oF + s * dF);
-            d.cv = *(const double*)(slot + ocv);
-            if constexpr (SHARED) {
+                for (int s = 0; s < KS; ++s) d.F[s] = *(const double*)(slot + oF + s * dF);
+                d.cv = *(const double*)(slot + ocv);
+            }
+            if constexpr (DIET) {
+                // (operands are read after the projection)
+            } else if constexpr (SHARED) {
 #pragma unroll
                 for (int s = 0; s < KS; ++s) d.C[s] = Csh[s];
                 d.Cu = Cush;
@@ -710,7 +728,38 @@ __global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVE
                 for (int s = 0; s < KS; ++s) d.dr[s] = *(const double*)(slot + G::OD + (4 * s + g) * 8);
             }
             d4 zin = zero4();
-            if constexpr (MODE == 2) {
+            if constexpr (DIET) {
+                // (see below) the projection first, with as little as possible alive: V, v wait in LDS, the step's operands are
+                // read from the ring afterwards -- the slot is refilled one projection later than otherwise, still a step ahead
+                double vx[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) vx[i] = sm[80 + i];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double* h = (const double*)(slot + oH[r]);
+                    double z = 0.0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) z = __builtin_fma(vx[i], h[i], z);
+                    zin[r] = zok[r] ? z : 0.0;
+                }
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    vst[s * 64 + lane] = Vxx[s];
+                    vst[(KS + s) * 64 + lane] = vxr[s];
+                }
+                ilqr_lds_sync();
+                psd_project_ns<KS + 1>(zin, a.zlive, 1e-3, jA, g, c, xst);
+                ilqr_lds_sync();
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    Vxx[s] = vst[s * 64 + lane];
+                    vxr[s] = vst[(KS + s) * 64 + lane];
+                    d.F[s] = *(const double*)(slot + oF + s * dF);
+                    d.C[s] = cst[s * 64 + lane];
+                }
+                d.cv = *(const double*)(slot + ocv);
+                d.Cu = cst[KS * 64 + lane];
+            } else if constexpr (MODE == 2) {
                 // vf_zz[4r+g][c] = sum_i v_x[i] H[pair][i], i ascending (the order of the register kernel's contraction); v_x is
                 // this wave's LDS row sm[80 ..], written by the previous step
                 double vx[N];
@@ -727,8 +776,10 @@ __global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVE
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // operands are in registers: the slot may be refilled
             if (j - D >= 0) dma(slot);
-            if constexpr (MODE == 2)
-                ilqr_step<KS, MODE, false, true>(Vxx, vxr, d, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, jA, nullptr, nullptr, nullptr, N, M, zin);
+            if constexpr (DIET)
+                ilqr_step<KS, MODE, false, 2>(Vxx, vxr, d, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, jA, nullptr, nullptr, nullptr, N, M, zin);
+            else if constexpr (MODE == 2)
+                ilqr_step<KS, MODE, false, 1>(Vxx, vxr, d, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, jA, nullptr, nullptr, nullptr, N, M, zin);
             else
                 ilqr_step<KS, MODE, false>(Vxx, vxr, d, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, nullptr, nullptr, nullptr, nullptr, N, M);
             if (--j < 0) return;

@@ -78,7 +78,13 @@ __device__ __forceinline__ d4 ns_symmetrise(const d4& v, double* T, int& flip, c
 
 // sign iteration on Z (scaled X) over K row groups; returns |X| = sign(X) X
 template <int K>
-__device__ __forceinline__ d4 ns_sign_times(d4 z, const d4& x, const d4& idr, double* T, int& flip, const int g, const int c) {
+__device__ __forceinline__ d4 ns_sign_times(d4 z, d4& x, const d4& idr, double* T, int& flip, const int g, const int c,
+                                            double* xstash = nullptr) {
+    if (xstash) {   // X leaves the registers for the duration of the iteration
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xstash[r * 64 + g * 16 + c] = x[r];
+        ns_sync();
+    }
     constexpr double QA = 3.4445, QB = -4.7750, QC = 2.0315;
     constexpr int MAX_PAIRS = 18, MAX_CUBIC = 12;
     int pairs = 0, cubic = 0;
@@ -112,18 +118,23 @@ __device__ __forceinline__ d4 ns_sign_times(d4 z, const d4& x, const d4& idr, do
             if (f < 1e-16 || cubic >= MAX_CUBIC) break;
         }
     }
+    if (xstash) {
+        ns_sync();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = xstash[r * 64 + g * 16 + c];
+    }
     return ns_op<K>(z, x);
 }
 
 // a (D layout: a[r] = A[4r+g][c]) is replaced by its projection.  T: NS_LDS_DOUBLES of LDS private to the wave.
 // KSZ: row groups that can hold live indices; the products run over the row groups that actually do (wave-uniform).
+// xstash: optional 256 doubles of wave-private LDS: X = a - eps I waits there during the iteration instead of in 8 registers (the
+// sweep kernel that wants a third wave per SIMD passes it)
 template <int KSZ>
 __device__ __forceinline__ void psd_project_ns(d4& a, const bool (&live)[4], const double eps, double* T, const int g,
-                                               const int c) {
+                                               const int c, double* xstash = nullptr) {
     int flip = 0;
-    d4 id, x;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) id[r] = live[r] ? 1.0 : 0.0;
+    d4 x;
     a = ns_symmetrise(a, T, flip, g, c);        // jnp.linalg.eigh symmetrises its input
     // An index whose row and column are exactly zero is an eigenvector with eigenvalue 0, decoupled from the rest: its projection
     // is eps on the diagonal, and it stays out of the iteration (idr).  Otherwise X would carry the eigenvalue -eps once per such
@@ -150,14 +161,14 @@ __device__ __forceinline__ void psd_project_ns(d4& a, const bool (&live)[4], con
         for (int r = 0; r < 4; ++r) z[r] = x[r] * inv;
         // nonzero columns all below row group `need`: the higher groups of every iterate stay zero and are skipped
         const int need = (colmask >> 12) ? 4 : (colmask >> 8) ? 3 : (colmask >> 4) ? 2 : 1;
-        if (KSZ >= 4 && need == 4) ax = ns_sign_times<(KSZ >= 4 ? 4 : KSZ)>(z, x, idr, T, flip, g, c);
-        else if (KSZ >= 3 && need == 3) ax = ns_sign_times<(KSZ >= 3 ? 3 : KSZ)>(z, x, idr, T, flip, g, c);
-        else if (KSZ >= 2 && need == 2) ax = ns_sign_times<(KSZ >= 2 ? 2 : KSZ)>(z, x, idr, T, flip, g, c);
-        else ax = ns_sign_times<1>(z, x, idr, T, flip, g, c);
+        if (KSZ >= 4 && need == 4) ax = ns_sign_times<(KSZ >= 4 ? 4 : KSZ)>(z, x, idr, T, flip, g, c, xstash);
+        else if (KSZ >= 3 && need == 3) ax = ns_sign_times<(KSZ >= 3 ? 3 : KSZ)>(z, x, idr, T, flip, g, c, xstash);
+        else if (KSZ >= 2 && need == 2) ax = ns_sign_times<(KSZ >= 2 ? 2 : KSZ)>(z, x, idr, T, flip, g, c, xstash);
+        else ax = ns_sign_times<1>(z, x, idr, T, flip, g, c, xstash);
     }
     d4 p;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) p[r] = __builtin_fma(0.5, x[r] + ax[r], eps * id[r]);
+    for (int r = 0; r < 4; ++r) p[r] = __builtin_fma(0.5, x[r] + ax[r], eps * (live[r] ? 1.0 : 0.0));
     a = ns_symmetrise(p, T, flip, g, c);
 }
 
