@@ -562,7 +562,10 @@ __global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVE
     // (256 doubles), the value function V, v (6 doubles per lane) and the shared cost Hessian (4 per lane)
     constexpr bool DIET = (MODE == 2) && (ZM_DDP_DMA_WAVES >= 3);
     constexpr int XST = DIET ? 256 : 0, VST = DIET ? 64 * 2 * KS : 0, CST = DIET ? 64 * (KS + 1) : 0;
-    __shared__ __attribute__((aligned(16))) char lds[SMO + ILQR_LDS_DOUBLES * 8 + (MODE == 2 ? NS_LDS_DOUBLES * 8 : 0) + (XST + VST + CST) * 8];
+#ifndef ZM_DDP_LDS_PAD   // occupancy experiments: extra bytes of LDS per wave in MODE 2
+#define ZM_DDP_LDS_PAD 0
+#endif
+    __shared__ __attribute__((aligned(16))) char lds[SMO + ILQR_LDS_DOUBLES * 8 + (MODE == 2 ? NS_LDS_DOUBLES * 8 + ZM_DDP_LDS_PAD : 0) + (XST + VST + CST) * 8];
     double* sm = (double*)(lds + SMO);
     double* jA = (double*)(lds + SMO + ILQR_LDS_DOUBLES * 8);   // MODE 2: transpose buffers of the sign iteration (ns16.h)
     double* xst = jA + NS_LDS_DOUBLES;
