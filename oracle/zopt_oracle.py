@@ -508,9 +508,9 @@ def quad_euler_step_torch(dt):
         one, zero = torch.ones_like(phi), torch.zeros_like(phi)
         E = torch.stack([torch.stack([one, sphi * tth, cphi * tth]), torch.stack([zero, cphi, -sphi]),
                          torch.stack([zero, sphi / cth, cphi / cth])])
-        flin = torch.tensor(QUAD_FORCE_LIN, dtype=x.dtype)
-        fquad = torch.tensor(QUAD_FORCE_QUAD, dtype=x.dtype)
-        mlin = torch.tensor(QUAD_MOMENT_LIN, dtype=x.dtype)
+        flin = torch.tensor(QUAD_FORCE_LIN, dtype=x.dtype, device=x.device)
+        fquad = torch.tensor(QUAD_FORCE_QUAD, dtype=x.dtype, device=x.device)
+        mlin = torch.tensor(QUAD_MOMENT_LIN, dtype=x.dtype, device=x.device)
         force_aero = flin * uvw + fquad * uvw ** 2
         d2xyz = torch.stack([-sth, sphi * cth, cphi * cth])
         force_total = QUAD_MASS * torch.stack([zero, zero, -u[0]]) + force_aero + QUAD_MASS * QUAD_G * d2xyz

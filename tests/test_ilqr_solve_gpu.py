@@ -225,8 +225,11 @@ def test_pytree_expansion_constructors():
     xf = xT[0, -1]
     assert vf.v.shape == () and abs(vf.v - xf @ Qf @ xf) <= 1e-12
     assert np.max(np.abs(vf.v_x - (Qf + Qf.T) @ xf)) <= 1e-12 and np.array_equal(vf.v_xx, Qf + Qf.T)
+    # a callable goes down the generic path (torch.func on the GPU, tests/test_generic_gpu.py); a non-callable is refused
+    ad = pytrees.AffineDynamics.from_function(lambda x, u: 2.0 * x, xT[0, 0], uT[0, 0])
+    assert np.array_equal(ad.f_x, 2.0 * np.eye(12)) and not ad.f_u.any()
     with pytest.raises(TypeError):
-        pytrees.AffineDynamics.from_function(lambda x, u: x, xT[0, 0], uT[0, 0])
+        pytrees.AffineDynamics.from_function("not a model", xT[0, 0], uT[0, 0])
 
 
 @pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 5, 6, 7])

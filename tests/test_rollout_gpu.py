@@ -166,10 +166,18 @@ def test_nan_wins_argmin(mods):
     assert np.array_equal(traj.uTraj[0], rt.uTraj, equal_nan=True)       # alpha = 1 (index 0)
 
 
-def test_unregistered_callable_is_rejected(mods):
+def test_callables_take_the_generic_path_and_non_callables_are_rejected(mods):
+    """a torch-traceable callable is rolled out by zopt_amd/generic.py (the reference's KAT, tests/test_ilqrUtils.py:7-22: x+ = x + u,
+    policy alpha * k); anything that is neither a registered model nor callable is refused"""
     ilqr, models, pt = mods
+    k = KATS["A6_trajectoryRollout"]
+    N = k["N"]
+    policy = pt.AffinePolicy(np.arange(N, dtype=np.float64)[:, None], np.zeros((N, 1, 1)))
+    prev = pt.Trajectory(np.zeros((N + 1, 1)), np.zeros((N, 1)))
+    t = ilqr.trajectoryRollout(np.array(k["x0"]), lambda x, u: x + u, policy, prev)
+    assert np.all(t.xTraj == np.array(k["alpha1"]["xTraj"])[:, None]) and np.all(t.uTraj == np.array(k["alpha1"]["uTraj"])[:, None])
     with pytest.raises(TypeError):
-        ilqr.trajectoryRollout(np.zeros(1), lambda x, u: x + u, pt.AffinePolicy(np.zeros((1, 1)), np.zeros((1, 1, 1))),
+        ilqr.trajectoryRollout(np.zeros(1), "no model", pt.AffinePolicy(np.zeros((1, 1)), np.zeros((1, 1, 1))),
                                pt.Trajectory(np.zeros((2, 1)), np.zeros((1, 1))))
 
 

@@ -20,6 +20,7 @@ try:
     import torch
 except Exception:  # pragma: no cover
     torch = None
+from . import generic as _generic  # noqa: E402  (torch.func producers in front of the HIP sweeps for callable models)
 
 
 def _fields(t):
@@ -141,9 +142,11 @@ _TRACE = None   # diagnostics: a list that receives (iteration, active trajector
 
 def _rollout(x0, dynFun, policy, trajPrev, alphas, costFun):
     """Shared driver of trajectoryRollout / forwardPass2 on the rollout_linesearch kernel."""
+    if _generic.is_callable_model(dynFun):
+        return _rollout_generic(x0, dynFun, policy, trajPrev, alphas, costFun)
     if not hasattr(dynFun, "c_struct"):
-        raise TypeError("dynFun must be a registered device model (zopt_amd.models.LinearModel / QuadcopterEuler); "
-                        "arbitrary Python callables cannot run inside a HIP kernel")
+        raise TypeError("dynFun must be a registered device model (zopt_amd.models.LinearModel / QuadcopterEuler) or a torch "
+                        "callable f(x, u) -> x+ (generic path, zopt_amd/generic.py)")
     if costFun is not None and not hasattr(costFun, "c_struct"):
         raise TypeError("costFun must be a registered zopt_amd.models.QuadraticCost")
     l, L = _fields(policy)
@@ -175,6 +178,42 @@ def _rollout(x0, dynFun, policy, trajPrev, alphas, costFun):
     _lib.check(rc, "rollout")
     traj = Trajectory(arr.result_like(xT, L), arr.result_like(uT, L))
     return traj, (arr.result_like(J, L) if J is not None else None)
+
+
+def _torch_costs(runningCost, terminalCost):
+    """torch callables (x, u) -> c, (x) -> cf from what the caller passed: torch callables as they are; a registered QuadraticCost (or
+    its bound methods) as x'Qx + u'Ru, x'Qf x on device copies of its matrices"""
+    for c in (runningCost, getattr(runningCost, "__self__", None)):
+        if isinstance(c, _models.QuadraticCost):
+            Q, R, Qf = (arr.to_device(M, torch.float64) for M in (c.Q, c.R, c.Qf))
+            return (lambda x, u: x @ Q @ x + u @ R @ u), (lambda x: x @ Qf @ x)
+    if not callable(runningCost) or not callable(terminalCost):
+        raise TypeError("runningCost / terminalCost must be torch callables or a registered zopt_amd.models.QuadraticCost")
+    return runningCost, terminalCost
+
+
+def _rollout_generic(x0, dynFun, policy, trajPrev, alphas, costFun):
+    """trajectoryRollout / forwardPass2 for a torch callable `dynFun(x, u) -> x+` (zopt_amd/generic.py); `costFun`: None, a
+    registered QuadraticCost, or an object with torch callables `.runningCost(x, u)` / `.terminalCost(x)` (CostFunction of the
+    reference, pytrees.py:27-38)."""
+    l, L = _fields(policy)
+    xPrev, uPrev = _fields(trajPrev)
+    shp = _shape(L)
+    lead, (N, m, n) = shp[:-3], shp[-3:]
+    dt = torch.float64
+    dx0, dl, dL, dxp, dup = (arr.to_device(X, dt) for X in (x0, l, L, xPrev, uPrev))
+    dx0, dl, dL = dx0.reshape(-1, n), dl.reshape(-1, N, m), dL.reshape(-1, N, m, n)
+    dxp, dup = dxp.reshape(-1, N + 1, n), dup.reshape(-1, N, m)
+    if costFun is None:
+        al = arr.to_device(np.asarray(alphas, dtype=np.float64), dt)
+        xs, us, _ = _generic.rollout(dx0, dynFun, dl, dL, dxp, dup, al)
+        xT, uT, J = xs[:, 0], us[:, 0], None
+    else:
+        rc, tc = _torch_costs(getattr(costFun, "runningCost", costFun), getattr(costFun, "terminalCost", costFun))
+        xT, uT, J = _generic.forward_pass2(dx0, dynFun, rc, tc, dl, dL, dxp, dup)
+        J = arr.result_like(J.reshape(lead), L)
+    traj = Trajectory(arr.result_like(xT.reshape(lead + (N + 1, n)), L), arr.result_like(uT.reshape(lead + (N, m)), L))
+    return traj, J
 
 
 def trajectoryRollout(x0, dynFun, policy, trajPrev, alpha=1):
@@ -349,10 +388,35 @@ def differentialDynamicProgramming(dynamics, runningCost, terminalCost, x0, uGue
     return _ilqr_or_ddp(dynamics, runningCost, terminalCost, x0, uGuess, maxIter, tol, ddp=True)
 
 
+def _ilqr_or_ddp_generic(dynamics, runningCost, terminalCost, x0, uGuess, maxIter, tol, ddp):
+    """The drivers for a torch callable `dynamics(x, u) -> x+` (and torch callables or a registered QuadraticCost for the costs):
+    zopt_amd/generic.py produces the expansions and the line-search rollouts with torch.func on the GPU, the sweeps and the PD
+    projections are the HIP kernels."""
+    rc, tc = _torch_costs(runningCost, terminalCost)
+    shp = _shape(uGuess)
+    lead, (N, m) = shp[:-2], shp[-2:]
+    n = _shape(x0)[-1]
+    if _shape(x0) != lead + (n,):
+        raise ValueError(f"x0 {_shape(x0)} / uGuess {shp} do not match")
+    dt = torch.float64
+    dx0 = arr.to_device(x0, dt).reshape(-1, n).contiguous()
+    dug = arr.to_device(uGuess, dt).reshape(-1, N, m).contiguous()
+    xT, uT, L, J, cv = _generic.solve(dynamics, rc, tc, dx0, dug, maxIter, tol, ddp)
+    tmpl = uGuess
+    xo, uo, Lo, Jo = (arr.result_like(o, tmpl) for o in (xT.reshape(lead + (N + 1, n)), uT.reshape(lead + (N, m)),
+                                                      L.reshape(lead + (N, m, n)), J.reshape(lead)))
+    co = arr.result_like(cv.reshape(lead), tmpl)
+    if not arr.is_torch(tmpl) and len(lead) == 0:
+        Jo, co = float(Jo), bool(co)
+    return Trajectory(xo, uo), Lo, Jo, co
+
+
 def _ilqr_or_ddp(dynamics, runningCost, terminalCost, x0, uGuess, maxIter, tol, ddp):
     model = dynamics
+    if _generic.is_callable_model(model):
+        return _ilqr_or_ddp_generic(dynamics, runningCost, terminalCost, x0, uGuess, maxIter, tol, ddp)
     if not hasattr(model, "c_struct"):
-        raise TypeError("dynamics must be a registered device model (zopt_amd.models.*)")
+        raise TypeError("dynamics must be a registered device model (zopt_amd.models.*) or a torch callable f(x, u) -> x+")
     cost = _registered_cost(runningCost, terminalCost)
     n, m = model.n, model.m
     shp = _shape(uGuess)

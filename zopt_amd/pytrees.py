@@ -23,7 +23,7 @@ def _expand(kind, fun, xTraj, uTraj):
     from . import _lib
     arr.require_gpu()
     if not hasattr(fun, "c_struct"):
-        raise TypeError("expected a registered device model / cost (zopt_amd.models.*), got " + type(fun).__name__)
+        return _expand_callable(kind, fun, xTraj, uTraj)
     n, m = fun.n, fun.m
     dt = torch.float64
     x = arr.to_device(xTraj, dt)
@@ -67,6 +67,32 @@ def _expand(kind, fun, xTraj, uTraj):
         else:     # terminal cost at x_N; a dummy time axis keeps _point's squeeze uniform
             outs = [v[:, None], v_x[:, None], v_xx.expand((B, 1, n, n)).contiguous()]
             outs = [o.reshape(lead + tuple(o.shape[1:])) for o in outs]
+    return [arr.result_like(o, xTraj) for o in outs]
+
+
+def _expand_callable(kind, fun, xTraj, uTraj):
+    """The expansions for torch callables (zopt_amd/generic.py: torch.func on the GPU, the part jax.jacobian / jax.hessian play in
+    the reference).  `fun`: a dynamics callable f(x, u) -> x+ for 'affine' / 'quadratic'; for 'cost' / 'terminal' a callable or an
+    object with `.runningCost(x, u)` / `.terminalCost(x)` (CostFunction, reference pytrees.py:27-38)."""
+    import torch
+    from . import _arrays as arr
+    from . import generic
+    if kind in ("affine", "quadratic") and not callable(fun):
+        raise TypeError("expected a registered device model or a torch callable f(x, u) -> x+, got " + type(fun).__name__)
+    x = arr.to_device(xTraj, torch.float64)
+    lead, (N1, n) = tuple(x.shape[:-2]), x.shape[-2:]
+    x = x.reshape(-1, N1, n)
+    if kind == "terminal":
+        tc = getattr(fun, "terminalCost", fun)
+        outs = [o[:, None] for o in generic.expand_terminal(tc, x[:, -1])]
+    else:
+        u = arr.to_device(uTraj, torch.float64)
+        u = u.reshape(-1, N1 - 1, u.shape[-1])
+        if kind == "cost":
+            outs = generic.expand_cost(getattr(fun, "runningCost", fun), x, u)
+        else:
+            outs = generic.expand_dynamics(fun, x, u, kind == "quadratic")
+    outs = [o.reshape(lead + tuple(o.shape[1:])) for o in outs]
     return [arr.result_like(o, xTraj) for o in outs]
 
 
