@@ -46,7 +46,9 @@ struct ExpandCost {
 // loads AND stores it took as long; one-wave or four-wave workgroups, one point or several per group, whole-line or column-strided
 // stores moved it by less than 10 %.  With the factored forms it writes its 1 536 B per point at the rate HBM takes them.
 constexpr int LIN_WAVES = 4;
-template <bool COST, bool QUAD>
+// WIND (quadcopter): constant NED wind -- the still-air closed forms are less than half as long; carrying both behind a run-time test
+// cost the kernel 40 registers (130 against 92) and with them two of its five waves per SIMD
+template <bool COST, bool QUAD, bool WIND = false>
 __global__ __launch_bounds__(64 * LIN_WAVES, 3) void linearize_dynamics_kernel(const zm_model_t md, const double* __restrict__ xTraj,
                                                                 const double* __restrict__ uTraj,
                                                                 const int* __restrict__ active, double* __restrict__ f,
@@ -130,8 +132,7 @@ __global__ __launch_bounds__(64 * LIN_WAVES, 3) void linearize_dynamics_kernel(c
             // e_j + dt d xd  (dt = 0: the derivative of xd itself, as model_step defines that case).
             const QuadAtoms a = quad_atoms(md, xv, uv);
             double o[12];
-            if (md.wind_ned[0] == 0.0 && md.wind_ned[1] == 0.0 && md.wind_ned[2] == 0.0) quad_jac_column<false>(j, a, o);   // still air
-            else quad_jac_column<true>(j, a, o);
+            quad_jac_column<WIND>(j, a, o);
 #pragma unroll
             for (int i = 0; i < 12; ++i) col[i] = (md.dt == 0.0) ? o[i] : __builtin_fma(md.dt, o[i], (i == j) ? 1.0 : 0.0);
             if (f && j == 0) {   // model_step's quadcopter branch, spelled out (the generic call drags the linear model's A, B loads
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(64 * LIN_WAVES) void quadratic_dynamics_pairs_kerne
 // closed forms of pairs 2j and 2j+1 (quad_hess_pair2), the 28 x 12 image of the point is gathered in LDS and leaves as whole lines.
 // Halves the instructions per point of quadratic_dynamics_pairs_kernel (whose 32-lane groups leave every second SIMD lane group idle
 // through the shared part).
+template <bool WIND>
 __global__ __launch_bounds__(64 * LIN_WAVES) void quad_hessian_pairs16_kernel(const zm_model_t md, const double* __restrict__ xTraj,
                                                                               const double* __restrict__ uTraj,
                                                                               const int* __restrict__ active, double* __restrict__ H,
@@ -341,8 +343,7 @@ __global__ __launch_bounds__(64 * LIN_WAVES) void quad_hessian_pairs16_kernel(co
     const QuadAtoms at = quad_atoms(md, xk, uk);
     if (active && active[traj] == 0) return;
     double o[24];
-    if (md.wind_ned[0] == 0.0 && md.wind_ned[1] == 0.0 && md.wind_ned[2] == 0.0) quad_hess_pair2<false>(j, at, o);   // still air
-    else quad_hess_pair2<true>(j, at, o);
+    quad_hess_pair2<WIND>(j, at, o);
     if (j < NPR / 2) {
 #pragma unroll
         for (int i = 0; i < 24; ++i) tile[q][j * 24 + i] = (md.dt == 0.0) ? o[i] : md.dt * o[i];   // x+ = x + dt xd  =>  d2 f = dt d2 xd
@@ -483,8 +484,12 @@ extern "C" int zm_linearize_dynamics_list_f64(const zm_model_t* model, const dou
     const long ngrp = (long)(list ? count : batch) * T;
     (void)npts;
     const dim3 grid((unsigned)((ngrp + GPB - 1) / GPB)), block(64 * zm::LIN_WAVES);
-    if (quad)
-        hipLaunchKernelGGL((zm::linearize_dynamics_kernel<false, true>), grid, block, 0, (hipStream_t)stream, md, xTraj, uTraj,
+    const bool windy = md.wind_ned[0] != 0.0 || md.wind_ned[1] != 0.0 || md.wind_ned[2] != 0.0;
+    if (quad && windy)
+        hipLaunchKernelGGL((zm::linearize_dynamics_kernel<false, true, true>), grid, block, 0, (hipStream_t)stream, md, xTraj, uTraj,
+                           (const int*)active, f, f_x, f_u, (long)batch, T, (const int*)list, (long)count, zm::ExpandCost{});
+    else if (quad)
+        hipLaunchKernelGGL((zm::linearize_dynamics_kernel<false, true, false>), grid, block, 0, (hipStream_t)stream, md, xTraj, uTraj,
                            (const int*)active, f, f_x, f_u, (long)batch, T, (const int*)list, (long)count, zm::ExpandCost{});
     else
         hipLaunchKernelGGL((zm::linearize_dynamics_kernel<false, false>), grid, block, 0, (hipStream_t)stream, md, xTraj, uTraj,
@@ -513,8 +518,12 @@ int expand_list(const zm_model_t* model, const zm_quadcost_t* cost, const double
     (void)npts;
     const dim3 grid((unsigned)((ngrp + GPB - 1) / GPB)), block(64 * LIN_WAVES);
     const ExpandCost ec{*cost, c_x, c_u, v_x};
-    if (quad)
-        hipLaunchKernelGGL((linearize_dynamics_kernel<true, true>), grid, block, 0, (hipStream_t)stream, md, xTraj, uTraj,
+    const bool windy = md.wind_ned[0] != 0.0 || md.wind_ned[1] != 0.0 || md.wind_ned[2] != 0.0;
+    if (quad && windy)
+        hipLaunchKernelGGL((linearize_dynamics_kernel<true, true, true>), grid, block, 0, (hipStream_t)stream, md, xTraj, uTraj,
+                           (const int*)active, (double*)nullptr, f_x, f_u, (long)batch, T, (const int*)list, (long)count, ec);
+    else if (quad)
+        hipLaunchKernelGGL((linearize_dynamics_kernel<true, true, false>), grid, block, 0, (hipStream_t)stream, md, xTraj, uTraj,
                            (const int*)active, (double*)nullptr, f_x, f_u, (long)batch, T, (const int*)list, (long)count, ec);
     else
         hipLaunchKernelGGL((linearize_dynamics_kernel<true, false>), grid, block, 0, (hipStream_t)stream, md, xTraj, uTraj,
@@ -618,8 +627,13 @@ extern "C" int zm_quadratic_dynamics_pairs_list_f64(const zm_model_t* model, con
     const long npts = (list ? (long)count : (long)batch) * T;
     if (md.kind == ZM_MODEL_QUADCOPTER) {
         constexpr int PPB16 = 4 * zm::LIN_WAVES;
-        hipLaunchKernelGGL(zm::quad_hessian_pairs16_kernel, dim3((unsigned)((npts + PPB16 - 1) / PPB16)), dim3(64 * zm::LIN_WAVES), 0,
-                           (hipStream_t)stream, md, xTraj, uTraj, (const int*)active, H, (long)batch, T, (const int*)list, (long)count);
+        const dim3 grid16((unsigned)((npts + PPB16 - 1) / PPB16)), block16(64 * zm::LIN_WAVES);
+        if (md.wind_ned[0] != 0.0 || md.wind_ned[1] != 0.0 || md.wind_ned[2] != 0.0)
+            hipLaunchKernelGGL(zm::quad_hessian_pairs16_kernel<true>, grid16, block16, 0, (hipStream_t)stream, md, xTraj, uTraj,
+                               (const int*)active, H, (long)batch, T, (const int*)list, (long)count);
+        else
+            hipLaunchKernelGGL(zm::quad_hessian_pairs16_kernel<false>, grid16, block16, 0, (hipStream_t)stream, md, xTraj, uTraj,
+                               (const int*)active, H, (long)batch, T, (const int*)list, (long)count);
         ZM_HIP_CHECK(hipGetLastError());
         return ZM_OK;
     }
