@@ -41,7 +41,8 @@ const char* zm_last_error(void);
  *             register-tile fp64 MFMA kernel for n <= 48, m <= 16 (47 M steps/s at (48, 16)); for 48 < n <= 64 an LDS-resident
  *             COVERAGE kernel that is correct but untuned -- 1.4 M steps/s at n = 64, a 30x cliff against n = 48: use fp32
  *             (zm_lqr_backward_f32: 62 M steps/s at (64, 16)) when that precision is acceptable;
- *   4 = fp32: zm_lqr_backward_f32, n <= 64, m <= 16 (n <= 12, m <= 4 are computed in fp64 and rounded once). */
+ *   4 = fp32: zm_lqr_backward_f32, n <= 64, m <= 16 (n in {8, 12}, m = 4 with 16-B aligned arrays: fp32 storage, fp64 arithmetic on
+ *             the LDS-DMA ring kernel -- 1.8e9 steps/s at (12, 4); the other shapes up to 16: the fp32 MFMA tile kernel). */
 int zm_lqr_backward_supported(int n, int m, int elem_size);
 
 /* Batched discrete finite-horizon LQR backward Riccati recursion (Joseph-form value update).
@@ -100,7 +101,8 @@ int zm_riccati_ode_f64(const double* A_s, const double* B_s, const double* Rinv_
                        double* V, int32_t* info, int64_t batch, int n, int m, int n_samples, int N, double T, double rtol,
                        double atol, int max_steps, void* stream);
 
-/* fp32 batched finite-horizon LQR backward sweep for large states (n <= 64, m <= 16): fp32 MFMA tile kernel.
+/* fp32 batched finite-horizon LQR backward sweep (n <= 64, m <= 16): the fp32 MFMA tile kernel; at the fast-path shapes (n in {8, 12},
+ * m = 4, 16-B aligned arrays) the LDS-DMA ring kernel on fp32 storage with fp64 arithmetic (the fp64 result rounded once).
  * Replaces: zopt/lqrUtils.py:144-173 discreteFiniteHorizonLqr when JAX runs in its default fp32 mode (x64 disabled, quirk Q8);
  *           the "large-state stress" shape n=64, m=16, T=200 of BASELINE configs[4].
  * in : A (batch,T,n,n)  B (batch,T,n,m)  Q (batch,T,n,n)  R (batch,T,m,m)   [device, C-contiguous float]

@@ -22,6 +22,10 @@ def main():
     for n, m, T in ((12, 4, 11), (8, 4, 7)):
         A, B, Q, R = problems.random_time_varying(9, T, n, m, seed=n + T)
         assert rel(lqrUtils.discreteFiniteHorizonLqr(A, B, Q, R, T), zo.discreteFiniteHorizonLqr(A, B, Q, R, T)) <= 1e-10
+    # fp32 arrays at the fast-path shape: K1 on fp32 storage (fp64 arithmetic) or, with ZOPT_AMD_LQR_F32=tile, the fp32 tile kernel
+    A, B, Q, R = problems.random_time_varying(6, 9, 12, 4, seed=21, dtype=np.float32)
+    L32 = lqrUtils.discreteFiniteHorizonLqr(A, B, Q, R, 9)
+    assert L32.dtype == np.float32 and rel(L32, zo.discreteFiniteHorizonLqr(*(X.astype(np.float64) for X in (A, B, Q, R)), 9)) <= 2e-5
     # large-state fp64 (tile / LDS coverage kernel)
     A, B, Q, R = problems.random_time_varying(2, 5, 24, 8, seed=5)
     assert rel(lqrUtils.discreteFiniteHorizonLqr(A, B, Q, R, 5), zo.discreteFiniteHorizonLqr(A, B, Q, R, 5)) <= 1e-10

@@ -165,3 +165,17 @@ def test_unsupported_shape_raises_valueerror(lqr):
     A, B, Q, R = problems.random_time_varying(1, 3, 65, 5, seed=2)      # beyond n <= 64, m <= 16
     with pytest.raises(ValueError):
         lqr.discreteFiniteHorizonLqr(A, B, Q, R, 3)
+
+
+@pytest.mark.parametrize("n,m,T,batch", [(12, 4, 50, 33), (8, 4, 7, 5), (12, 4, 1, 3), (12, 4, 2, 2)])
+def test_fp32_storage_fast_path_is_fp64_arithmetic_on_fp32_arrays(lqr, n, m, T, batch):
+    """fp32 inputs at the fast-path shapes run K1 on 4-byte ring elements (zm_lqr_backward_f32 -> lqr_backward_dma_f64<..., float>):
+    operands widened as they are read, fp64 arithmetic, L_k narrowed as it is stored.  So the result is the fp64 oracle's on the same
+    (fp32-representable) inputs rounded once -- to within one fp32 ulp -- on every ring phase (horizons 1, 2, 7, 50); and the fp32 tile
+    kernel (ZOPT_AMD_LQR_F32=tile, fp32 arithmetic) stays within the fp32 tolerance of it."""
+    A, B, Q, R = problems.random_time_varying(batch, T, n, m, seed=n + T, dtype=np.float32)
+    L = lqr.discreteFiniteHorizonLqr(A, B, Q, R, T)
+    assert L.dtype == np.float32 and L.shape == (batch, T, m, n)
+    Lr = zo.discreteFiniteHorizonLqr(*(X.astype(np.float64) for X in (A, B, Q, R)), T)
+    ulp = np.spacing(np.abs(Lr).astype(np.float32)).astype(np.float64)
+    assert np.all(np.abs(L.astype(np.float64) - Lr) <= 0.5 * ulp + 1e-12 * np.abs(Lr).max())

@@ -156,10 +156,44 @@ def config4_tiled(batch=2048, T=200, n=64, m=16, reps=3, fp64=False):
     return out
 
 
+def config1_fp32_arrays(batch=4096, T=50, steps=200, warmup=50):
+    """BASELINE.md section 3 row "n=12, m=4, fp32" (1 600 B per horizon step): configs[1]'s problem on fp32 arrays.  K1 on fp32 storage with
+    fp64 arithmetic (zm_lqr_backward_f32 at the fast-path shapes): half the HBM bytes of the headline call, same arithmetic."""
+    import ctypes
+    import torch
+    from zopt_amd import _lib
+    n, m = 12, 4
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rn = lambda *s: torch.randn(*s, device="cuda", dtype=torch.float32, generator=g)
+    A, B = rn(batch, T, n, n) * (0.9 / n ** 0.5), rn(batch, T, n, m)
+    Mq, Mr = rn(batch, T, n, n), rn(batch, T, m, m)
+    Q = (Mq @ Mq.transpose(-1, -2) / n + torch.eye(n, device="cuda")).contiguous()
+    R = (Mr @ Mr.transpose(-1, -2) / m + torch.eye(m, device="cuda")).contiguous()
+    L = torch.empty((batch, T, m, n), device="cuda", dtype=torch.float32)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lib = _lib.lib()
+    call = lambda: _lib.check(lib.zm_lqr_backward_f32(A.data_ptr(), B.data_ptr(), Q.data_ptr(), R.data_ptr(), L.data_ptr(), batch, T, n, m, st), "f32")
+    for _ in range(warmup):
+        call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / steps
+    bps = 4 * (2 * n * n + n * m + m * m + m * n)
+    return {"workload": f"configs[1] on fp32 arrays: discreteFiniteHorizonLqr n=12 m=4 T={T}, {batch} trajectories, fp32 storage / fp64 arithmetic",
+            "us_per_launch": t * 1e6, "horizon_steps_per_s": batch * T / t, "bytes_per_step": bps,
+            "algorithmic_GBps": batch * T * bps / t / 1e9, "frac_of_hbm_peak": batch * T * bps / t / 8e12, "finite": bool(torch.isfinite(L).all().item())}
+
+
 def run_all(budget_s=25.0):
     """Every secondary measurement, skipping what no longer fits the time budget (the bench line must stay within minutes)."""
     out, t0 = {}, time.perf_counter()
-    for key, fn in (("configs[2]_lqrMpc", lambda: config2_mpc()),
+    for key, fn in (("configs[1]_fp32_arrays", lambda: config1_fp32_arrays()),
+                    ("configs[2]_lqrMpc", lambda: config2_mpc()),
                     ("configs[3]_iterativeLqr", lambda: config3_ilqr(ddp=False, reps=3)),
                     ("configs[3]_differentialDynamicProgramming", lambda: config3_ilqr(ddp=True, reps=2)),
                     ("configs[4]_lqr_n64_fp32", lambda: config4_tiled())):

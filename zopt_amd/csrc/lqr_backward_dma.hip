@@ -31,11 +31,14 @@
 
 namespace zm {
 
-template <int N, int M>
+// ES: bytes per stored element (8: fp64 arrays; 4: fp32 arrays -- the arithmetic is fp64 either way, operands are widened as they
+// are read from the ring and L_k is narrowed as it is stored: half the HBM bytes for fp32 callers, no conversion passes)
+template <int N, int M, int ES = 8>
 struct DmaGeom {
     static constexpr int KS = N / 4;
     static constexpr int NP = N;
-    static constexpr int CA = N * N / 2, CB = N * M / 2, CR = M * M / 2;  // 16-B chunks per step
+    static constexpr int EPC = 16 / ES;                                          // elements per 16-B chunk
+    static constexpr int CA = N * N / EPC, CB = N * M / EPC, CR = M * M / EPC;   // 16-B chunks per step
     static constexpr int CT = 2 * CA + CB + CR;
     static constexpr int NI = (CT + 63) / 64;   // DMA wave-instructions per step
     static constexpr int SLOT = NI * 1024;      // bytes per ring slot
@@ -45,9 +48,9 @@ struct DmaGeom {
     static_assert(SLOT - OZ >= 16, "slot needs zero padding");
 };
 
-template <int N, int M, int D>
+template <int N, int M, int D, int ES = 8>
 struct DmaState {
-    using G = DmaGeom<N, M>;
+    using G = DmaGeom<N, M, ES>;
     const char* p[G::NI];  // per-lane source address of the next step to fetch, one per DMA instruction
     int st[G::NI];         // per-lane byte stride between consecutive steps of that array (0 for the zero source)
     int oF, dF;            // LDS byte offset of F[g][c] in a slot and its K-step stride (A lanes 4n*8, B lanes 4m*8)
@@ -57,9 +60,9 @@ struct DmaState {
 // AUX: cache-policy bits of the DMA (sc0 = 1, nt = 2, sc1 = 16).  The product streams its inputs non-temporally (2): every byte
 // is read exactly once, and keeping it out of the L2 / Infinity Cache replacement order is worth 10 % of the kernel's time
 // (tools/k1_lab.hip: 144 -> 128 us per launch; the memory-only variant of the same access pattern 134 -> 119 us).
-template <int N, int M, int D, int AUX = 2>
-__device__ __forceinline__ void dma_issue(DmaState<N, M, D>& a, char* slot) {
-    using G = DmaGeom<N, M>;
+template <int N, int M, int D, int AUX = 2, int ES = 8>
+__device__ __forceinline__ void dma_issue(DmaState<N, M, D, ES>& a, char* slot) {
+    using G = DmaGeom<N, M, ES>;
 #pragma unroll
     for (int i = 0; i < G::NI; ++i) {
         __builtin_amdgcn_global_load_lds((glb_void_t*)a.p[i], (lds_void_t*)(slot + i * 1024), 16, 0, AUX);
@@ -97,13 +100,21 @@ __device__ __forceinline__ void k1_lds_sync() {
     }
 }
 
-template <int N, int M, int D, bool G4, int X = 0, int W = 1, int WPS = 4>
-__global__ __launch_bounds__(64 * W, WPS) void lqr_backward_dma_f64(const double* __restrict__ A,
-                                                                  const double* __restrict__ B,
-                                                                  const double* __restrict__ Q,
-                                                                  const double* __restrict__ R, double* __restrict__ L,
+// one stored element of the ring, widened to the arithmetic type
+template <typename IO>
+__device__ __forceinline__ double ring_read(const char* p) {
+    return (double)*(const IO*)p;
+}
+
+template <int N, int M, int D, bool G4, int X = 0, int W = 1, int WPS = 4, typename IO = double>
+__global__ __launch_bounds__(64 * W, WPS) void lqr_backward_dma_f64(const IO* __restrict__ A,
+                                                                  const IO* __restrict__ B,
+                                                                  const IO* __restrict__ Q,
+                                                                  const IO* __restrict__ R, IO* __restrict__ L,
                                                                   const int T, const long batch) {
-    using G = DmaGeom<N, M>;
+    constexpr int ES = (int)sizeof(IO);
+    static_assert(ES == 8 || X == 0, "the lab's diagnostic variants are fp64-storage only");
+    using G = DmaGeom<N, M, ES>;
     constexpr int KS = G::KS, NI = G::NI, SLOT = G::SLOT;
     constexpr int kAux = (X & 16) ? ((X >> 8) & 31) : 2;   // lab: bit 16 selects the policy in bits 8..12; product: nt
     constexpr int nn = N * N, nm = N * M, mm = M * M;
@@ -123,7 +134,7 @@ __global__ __launch_bounds__(64 * W, WPS) void lqr_backward_dma_f64(const double
     const bool cA = c < N;                    // state column
     const bool cB = (c >= N) && (c < N + M);  // control column
 
-    DmaState<N, M, D> a;
+    DmaState<N, M, D, ES> a;
     {
         const long last = ltraj * T + (T - 1);
         const char* At = (const char*)(A + last * nn);
@@ -135,16 +146,16 @@ __global__ __launch_bounds__(64 * W, WPS) void lqr_backward_dma_f64(const double
             const int q = i * 64 + lane;  // 16-B chunk index inside the step's [A|B|Q|R|0-pad] image
             if (q < G::CA) {
                 a.p[i] = At + q * 16;
-                a.st[i] = nn * 8;
+                a.st[i] = nn * ES;
             } else if (q < G::CA + G::CB) {
                 a.p[i] = Bt + (q - G::CA) * 16;
-                a.st[i] = nm * 8;
+                a.st[i] = nm * ES;
             } else if (q < 2 * G::CA + G::CB) {
                 a.p[i] = Qt + (q - G::CA - G::CB) * 16;
-                a.st[i] = nn * 8;
+                a.st[i] = nn * ES;
             } else if (q < G::CT) {
                 a.p[i] = Rt + (q - 2 * G::CA - G::CB) * 16;
-                a.st[i] = mm * 8;
+                a.st[i] = mm * ES;
             } else {  // idle lanes: zero-fill the slot's padding
                 a.p[i] = (const char*)zm_zero_src;
                 a.st[i] = 0;
@@ -154,21 +165,21 @@ __global__ __launch_bounds__(64 * W, WPS) void lqr_backward_dma_f64(const double
     // MFMA operand addresses inside a slot.  Lanes outside a matrix either read finite don't-care data (they only
     // ever feed padding rows/columns of the tile) or, where a true zero is required (R's accumulator init under
     // the state columns), the zero padding.
-    a.oF = cA ? (G::OA + (g * N + c) * 8) : cB ? (G::OB + (g * M + (c - N)) * 8) : G::OZ;
-    a.dF = cA ? 4 * N * 8 : cB ? 4 * M * 8 : 0;
-    a.oQ = G::OQ + (g * N + (cA ? c : 0)) * 8;
-    a.oRm = cB ? (G::OR + (g * M + (c - N)) * 8) : G::OZ;
-    a.oBR = cA ? (G::OB + (c * M + g) * 8) : cB ? (G::OR + ((c - N) * M + g) * 8) : G::OZ;
+    a.oF = cA ? (G::OA + (g * N + c) * ES) : cB ? (G::OB + (g * M + (c - N)) * ES) : G::OZ;
+    a.dF = cA ? 4 * N * ES : cB ? 4 * M * ES : 0;
+    a.oQ = G::OQ + (g * N + (cA ? c : 0)) * ES;
+    a.oRm = cB ? (G::OR + (g * M + (c - N)) * ES) : G::OZ;
+    a.oBR = cA ? (G::OB + (c * M + g) * ES) : cB ? (G::OR + ((c - N) * M + g) * ES) : G::OZ;
     const int oYBw = YBO + (g * M + (c - N)) * 8;           // Y_B[4r+g][c-n]   (+ r*4*M*8), lanes cB
     const int oYBr = YBO + ((cA ? c : 0) * M + g) * 8;      // Y_B[c][g]        A operand of Y_B (-L)
     const int oYBa = YBO + (g * M + (c & 3)) * 8;           // Y_B[4s+g][c & 3] (+ s*4*M*8): A operand of the 4x4x4 blocks (G4)
     const bool vL = cA;                                     // (g < M always: M == 4)
-    double* pL = L + ((((X >> 19) & 1) ? (traj & 63) : traj) * T + (T - 1)) * nm + g * N + c;
+    IO* pL = L + ((((X >> 19) & 1) ? (traj & 63) : traj) * T + (T - 1)) * nm + g * N + c;
 
     // prologue: fill the ring with steps T-1 .. T-D
 #pragma unroll
     for (int i = 0; i < D; ++i)
-        if (((X >> 20) & 1) == 0 && T - 1 - i >= 0) dma_issue<N, M, D, kAux>(a, lds + i * SLOT);
+        if (((X >> 20) & 1) == 0 && T - 1 - i >= 0) dma_issue<N, M, D, kAux, ES>(a, lds + i * SLOT);
 
     double V[KS];
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, acc[5] = {0, 0, 0, 0, 0};
@@ -183,13 +194,13 @@ __global__ __launch_bounds__(64 * W, WPS) void lqr_backward_dma_f64(const double
             wait_for_step<NI, D, (X & 8) != 0>(j, T);
             d4 f4 = zero4(), q4 = zero4();
 #pragma unroll
-            for (int s = 0; s < KS; ++s) f4[s] = *(const double*)(slot + a.oF + s * a.dF);
+            for (int s = 0; s < KS; ++s) f4[s] = ring_read<IO>(slot + a.oF + s * a.dF);
 #pragma unroll
-            for (int s = 0; s < KS; ++s) q4[s] = *(const double*)(slot + a.oQ + s * (4 * N * 8));
-            const double rm = *(const double*)(slot + a.oRm);
-            const double br = *(const double*)(slot + a.oBR);
+            for (int s = 0; s < KS; ++s) q4[s] = ring_read<IO>(slot + a.oQ + s * (4 * N * ES));
+            const double rm = ring_read<IO>(slot + a.oRm);
+            const double br = ring_read<IO>(slot + a.oBR);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // operands are in registers: the slot may be refilled
-            if (((X >> 20) & 1) == 0 && j - D >= 0) dma_issue<N, M, D, kAux>(a, slot);
+            if (((X >> 20) & 1) == 0 && j - D >= 0) dma_issue<N, M, D, kAux, ES>(a, slot);
             ZM_STAMP(st1)
 #ifdef ZM_K1_LAB
             if constexpr ((X & 32) != 0) {   // memory only: the access pattern's own time (no MFMA, no solve)
@@ -280,8 +291,8 @@ __global__ __launch_bounds__(64 * W, WPS) void lqr_backward_dma_f64(const double
                 else if constexpr (SP == 4) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(pL), "v"(lv) : "memory");
                 else
 #endif
-                if constexpr ((X & 64) != 0) __builtin_nontemporal_store(lv, pL);
-                else *pL = lv;
+                if constexpr ((X & 64) != 0) __builtin_nontemporal_store((IO)lv, pL);
+                else *pL = (IO)lv;
             }
             pL -= nm;
             ZM_STAMP(st4)
@@ -335,6 +346,24 @@ static int launch_dma(const double* A, const double* B, const double* Q, const d
         hipLaunchKernelGGL((lqr_backward_dma_f64<N, M, 3, true>), grid, block, 0, stream, A, B, Q, R, L, T, (long)batch);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
+}
+
+// fp32 arrays in and out, fp64 arithmetic (the same kernel instantiated on 4-byte ring elements)
+template <int N, int M>
+static int launch_dma_f32io(const float* A, const float* B, const float* Q, const float* R, float* L, int64_t batch, int T,
+                            hipStream_t stream) {
+    hipLaunchKernelGGL((lqr_backward_dma_f64<N, M, 3, true, 0, 1, 4, float>), dim3((unsigned)batch), dim3(64), 0, stream, A, B, Q, R, L,
+                       T, (long)batch);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+int lqr_backward_dma_dispatch_f32io(const float* A, const float* B, const float* Q, const float* R, float* L, int64_t batch, int T,
+                                    int n, int m, hipStream_t stream) {
+    const uintptr_t al = (uintptr_t)A | (uintptr_t)B | (uintptr_t)Q | (uintptr_t)R;
+    if (al & 15) return ZM_EUNSUPPORTED;
+    if (n == 12 && m == 4) return launch_dma_f32io<12, 4>(A, B, Q, R, L, batch, T, stream);
+    if (n == 8 && m == 4) return launch_dma_f32io<8, 4>(A, B, Q, R, L, batch, T, stream);
+    return ZM_EUNSUPPORTED;
 }
 
 // Returns ZM_EUNSUPPORTED when the shape / alignment is not covered so that the caller falls back.

@@ -25,6 +25,11 @@
 
 #include <cstdlib>
 
+namespace zm {
+int lqr_backward_dma_dispatch_f32io(const float* A, const float* B, const float* Q, const float* R, float* L, int64_t batch, int T,
+                                    int n, int m, hipStream_t stream);
+}
+
 extern "C" int zm_lqr_backward_f32(const float* A, const float* B, const float* Q, const float* R, float* L, int64_t batch,
                                    int T, int n, int m, void* stream) {
     if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
@@ -35,6 +40,17 @@ extern "C" int zm_lqr_backward_f32(const float* A, const float* B, const float* 
     if (batch > 0x7fffffffLL) return zm::set_error(ZM_EINVAL, "zm_lqr_backward_f32: batch too large for one launch");
     if (T == 0) return ZM_OK;
     hipStream_t st = (hipStream_t)stream;
+    {   // the small fast-path shapes: K1 (LDS-DMA ring, tile-16 fp64 MFMA) on fp32 arrays -- fp32 storage, fp64 arithmetic, half the
+        // HBM bytes of the fp64 call and no conversion passes (lqr_backward_dma.hip).  ZOPT_AMD_LQR_F32=tile: the fp32 tile kernel.
+        static const bool tile_only = [] {
+            const char* e = getenv("ZOPT_AMD_LQR_F32");
+            return e && e[0] == 't';
+        }();
+        if (!tile_only) {
+            const int rc = zm::lqr_backward_dma_dispatch_f32io(A, B, Q, R, L, batch, T, n, m, st);
+            if (rc != ZM_EUNSUPPORTED) return rc;
+        }
+    }
     switch ((n + 15) / 16) {
         case 1: return zm::launch_tiled<zm::TileF32, 1>(A, B, Q, R, L, batch, T, n, m, st);
         case 2: return zm::launch_tiled<zm::TileF32, 2>(A, B, Q, R, L, batch, T, n, m, st);

@@ -54,9 +54,10 @@ def discreteFiniteHorizonLqr(A, B, Q, R, N):
     if N < 1:
         _shape_error("N must be >= 1")
     fp32_in = (arr.is_torch(A) and A.dtype == torch.float32) or (not arr.is_torch(A) and np.asarray(A).dtype == np.float32)
-    # dtype follows the input arrays (quirk Q8).  fp32 inputs: the small shapes (n <= 12, m <= 4) are computed in fp64 on the
-    # tile-16 kernel and rounded once on output; larger ones (n <= 64, m <= 16) run the native fp32 MFMA tile kernel.
-    native32 = fp32_in and (n > 12 or m > 4)
+    # dtype follows the input arrays (quirk Q8).  fp32 inputs go to zm_lqr_backward_f32 as they are: the fast-path shapes (n in {8, 12},
+    # m = 4) run K1 on fp32 storage with fp64 arithmetic, larger ones (n <= 64, m <= 16) the fp32 MFMA tile kernel; the remaining small
+    # shapes are computed in fp64 on the tile-16 kernel and rounded once on output.
+    native32 = fp32_in and (n > 12 or m > 4 or ((n in (8, 12)) and m == 4))
     dt = torch.float32 if native32 else torch.float64
     dev = [arr.to_device(X, dt) for X in (A, B, Q, R)]
     batch = 1
