@@ -94,3 +94,48 @@ def test_dare_and_psd_sweeps(mods):
         w, vv = np.linalg.eigh(Amat)
         ref = (vv * np.maximum(w, 1e-3)[:, None, :]) @ np.swapaxes(vv, -1, -2)
         assert np.max(np.abs(P - ref)) <= 1e-11 * max(1.0, np.max(np.abs(ref))), ("psd", case, k, b)
+
+
+def test_quadcopter_expansions_random_points_horizons_and_wind(mods):
+    """K7 for the quadcopter (closed forms generated by sympy, quad_derivs_gen.h; 16 lanes per point, LDS-transposed stores) over random
+    horizons, batch sizes that do not fill a workgroup, large attitude angles and wind: Jacobians against complex-step differentiation
+    of the oracle model, packed second derivatives against the hyper-dual evaluation of the full-tensor entry point."""
+    import ctypes
+    import torch
+    from zopt_amd import _lib, models
+    _, _, pt = mods
+    rng = np.random.default_rng(77)
+    lib = _lib.lib()
+    for case in range(12):
+        b, N = int(rng.integers(1, 40)), int(rng.integers(1, 23))
+        wind = (0.0, 0.0, 0.0) if case % 3 else tuple(rng.uniform(-4, 4, 3))
+        dt = 0.0 if case == 5 else float(rng.uniform(0.02, 0.2))
+        model = models.QuadcopterEuler(dt, wind_ned=wind)
+        xT = rng.standard_normal((b, N + 1, 12)) * np.array([3, 3, 3, 1, 1, 1, 0.9, 0.9, 3.0, 5, 5, 5])
+        uT = np.array([9.807, 0, 0, 0]) + rng.standard_normal((b, N, 4))
+        ad = pt.AffineDynamics.from_trajectory(model, pt.Trajectory(xT, uT))
+        h = 1e-30
+        for (bi, k) in [(0, 0), (b - 1, N - 1), (int(rng.integers(0, b)), int(rng.integers(0, N)))]:
+            J = np.zeros((12, 16))
+            for j in range(16):
+                z = np.concatenate([xT[bi, k], uT[bi, k]]).astype(complex)
+                z[j] += 1j * h
+                xd = zo.quad_inertialDynamics(z[:12], z[12:], np.array(wind))
+                J[:, j] = np.imag(z[:12] + dt * xd if dt else xd) / h
+            assert np.max(np.abs(ad.f_x[bi, k] - J[:, :12])) <= 1e-11 * max(1.0, np.abs(J).max()), (case, bi, k)
+            assert np.max(np.abs(ad.f_u[bi, k] - J[:, 12:])) <= 1e-11 * max(1.0, np.abs(J).max()), (case, bi, k)
+        # packed second derivatives (closed forms) against the full tensors (hyper-dual numbers)
+        md = model.c_struct()
+        dx, du = torch.as_tensor(xT, device="cuda"), torch.as_tensor(uT, device="cuda")
+        H = torch.full((b, N, 28, 12), float("nan"), dtype=torch.float64, device="cuda")
+        f_xx = torch.empty((b, N, 12, 12, 12), dtype=torch.float64, device="cuda")
+        pairs, npairs = (ctypes.c_int32 * 64)(), ctypes.c_int32(0)
+        _lib.check(lib.zm_model_hessian_pairs(ctypes.addressof(md), ctypes.addressof(pairs), ctypes.addressof(npairs)), "pairs")
+        _lib.check(lib.zm_quadratic_dynamics_pairs_list_f64(ctypes.addressof(md), dx.data_ptr(), du.data_ptr(), None, 0, None, H.data_ptr(), b, N, None), "packed")
+        _lib.check(lib.zm_quadratic_dynamics_f64(ctypes.addressof(md), dx.data_ptr(), du.data_ptr(), None, f_xx.data_ptr(), None, None, b, N, None), "full")
+        torch.cuda.synchronize()
+        Hn, F = H.cpu().numpy(), f_xx.cpu().numpy()
+        ab = np.array(pairs[:56]).reshape(28, 2)
+        scale = max(1.0, np.abs(F).max())
+        for p, (a_, b_) in enumerate(ab):
+            assert np.max(np.abs(Hn[:, :, p, :] - F[:, :, :, a_, b_])) <= 1e-12 * scale, (case, p)
