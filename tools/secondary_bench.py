@@ -109,7 +109,7 @@ def tiled_mfma_per_step(n):
     return 4 * nt * nt + 4 * nt * (nt + 1) + 4 * nt ** 3 + 4 * nt * nt + 4 * nt + 4 * nt * nt + 4 * nt * nt + 4 * nt ** 3
 
 
-def config4_tiled(batch=2048, T=200, n=64, m=16, reps=3, fp64=False):
+def config4_tiled(batch=2048, T=200, n=64, m=16, reps=10, fp64=False):
     import torch
     from zopt_amd import _lib
     b = batch
@@ -133,14 +133,14 @@ def config4_tiled(batch=2048, T=200, n=64, m=16, reps=3, fp64=False):
     call()
     torch.cuda.synchronize()
     ts = []
-    for _ in range(reps):
+    for _ in range(reps):   # ten 6-ms launches: the clock has left its idle state by the fourth (the first three read 6.6 / 6.4 / 6.2 ms)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         call()
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e-3)
-    best = min(ts)
+    best = _median(sorted(ts)[: max(1, len(ts) // 2)])   # median of the faster half: steady state, not the single best launch
     steps = b * T
     bytes_step = (8 if fp64 else 4) * (2 * n * n + 2 * n * m + m * m)
     tflops = steps * tiled_mfma_per_step(n) * 2048 / best / 1e12
