@@ -37,3 +37,16 @@ extern "C" void quad_hessian_pairs(const double* x, const double* u, const doubl
         for (int i = 0; i < 12; ++i) H[p * 12 + i] = o[i];
     }
 }
+
+// the packed image of [f_x | f_u] = I + dt d xd / d z (quad_jac_column_packed) and the position table that goes with it
+extern "C" int quad_jacobian_packed(const double* x, const double* u, const double* w, int still_air, double dt, double* t /* >= 60 */,
+                                    unsigned char* pos /* (12, 16) */) {
+    const zm::QuadAtoms a = atoms(x, u, w);
+    for (int j = 0; j < 16; ++j) {
+        if (still_air) zm::quad_jac_column_packed<false>(j, a, dt, t);
+        else zm::quad_jac_column_packed<true>(j, a, dt, t);
+    }
+    const unsigned char* p = still_air ? zm::QUAD_JPOS_STILL : zm::QUAD_JPOS_WIND;
+    for (int e = 0; e < 192; ++e) pos[e] = p[e];
+    return still_air ? zm::QUAD_NJ_STILL : zm::QUAD_NJ_WIND;
+}

@@ -27,6 +27,8 @@ def shim(tmp_path_factory):
     dp = ctypes.POINTER(ctypes.c_double)
     lib.quad_jacobian.argtypes = [dp, dp, dp, ctypes.c_int, dp]
     lib.quad_hessian_pairs.argtypes = [dp, dp, dp, ctypes.c_int, ctypes.c_int, dp]
+    lib.quad_jacobian_packed.argtypes = [dp, dp, dp, ctypes.c_int, ctypes.c_double, dp, ctypes.POINTER(ctypes.c_ubyte)]
+    lib.quad_jacobian_packed.restype = ctypes.c_int
     return lib
 
 
@@ -104,6 +106,25 @@ def test_second_derivatives_with_wind_match_differences_of_the_jacobian(shim):
             seen[a, b] = seen[b, a] = True
             assert np.max(np.abs(H[p] - full[:, a, b])) <= 1e-7 * scale, (p, a, b)
         assert np.max(np.abs(full[:, ~seen])) <= 1e-7 * scale
+
+
+@pytest.mark.parametrize("wind", [(0.0, 0.0, 0.0), (3.0, 1.0, -0.5)])
+def test_packed_jacobian_image_rebuilds_the_full_matrices(shim, wind):
+    """quad_jac_column_packed + QUAD_JPOS_*: the packed entries at their positions and the identity everywhere else are
+    [f_x | f_u] = I + dt d xd / d z (the form the expansion kernel writes and the sweep kernels read)"""
+    w, dt = np.array(wind), 0.1
+    still = 0 if np.any(w) else 1
+    for x, u in _points(5, 8):
+        t = np.full(64, np.nan)
+        pos = np.zeros(192, dtype=np.uint8)
+        nj = shim.quad_jacobian_packed(_p(x), _p(u), _p(w), still, dt, _p(t), pos.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)))
+        pos = pos.reshape(12, 16)
+        assert nj == (56 if still else 59) and sorted(pos[pos != 255].tolist()) == list(range(nj)) and np.all(np.isfinite(t[:nj]))
+        F = np.hstack([np.eye(12), np.zeros((12, 4))])
+        F[pos != 255] = t[pos[pos != 255]]
+        ref = np.hstack([np.eye(12), np.zeros((12, 4))]) + dt * _complex_step_jacobian(x, u, w)
+        assert np.max(np.abs(F - ref)) <= 1e-13 * max(1.0, np.abs(ref).max())
+        assert np.all((ref != np.hstack([np.eye(12), np.zeros((12, 4))])) <= (pos != 255))     # nothing outside the packed set moves
 
 
 def test_header_is_what_the_generator_writes(tmp_path):

@@ -88,9 +88,10 @@ class Printer(C99CodePrinter):
         return repr(float(r))
 
 
-def emit_body(fh, table, pr, ind):
+def emit_body(fh, table, pr, ind, packed=None):
     """table: {case -> [(i, expr)]}.  One CSE over everything; a temporary that serves several cases is computed by every lane before
-    the switch, one that serves a single case inside it."""
+    the switch, one that serves a single case inside it.  packed = {(i, case) -> position}: instead of o[i] = expr the case writes
+    t[position] = dt * expr + (i == case) -- the packed image of column `case` of [f_x | f_u] = I + dt d xd / d z."""
     keys = [(c, i) for c in sorted(table) for i, _ in table[c]]
     exprs = [e for c in sorted(table) for _, e in table[c]]
     temps, outs = sp.cse(exprs, symbols=sp.numbered_symbols("t"), optimizations="basic")
@@ -117,8 +118,10 @@ def emit_body(fh, table, pr, ind):
             if use[t] == {c}:
                 fh.write(f"{ind}        const double {t} = {pr.doprint(e)};\n")
         for (cc, i), o in zip(keys, outs):
-            if cc == c:
+            if cc == c and packed is None:
                 fh.write(f"{ind}        o[{i}] = {pr.doprint(o)};\n")
+            elif cc == c:
+                fh.write(f"{ind}        t[{packed[(i, c)]}] = (dt == 0.0) ? ({pr.doprint(o)}) : __builtin_fma(dt, {pr.doprint(o)}, {1.0 if i == c else 0.0});\n")
         fh.write(f"{ind}    }} break;\n")
     fh.write(f"{ind}    default: break;\n{ind}}}\n")
     shared_ops = sum(sp.count_ops(e) for t, e in temps if len(use[t]) > 1)
@@ -184,6 +187,30 @@ def main():
             fh.write("    } else {\n")
             stats[(fn, False)] = emit_body(fh, table(False), pr, "        ")
             fh.write("    }\n}\n\n")
+        # packed Jacobians: the structurally nonzero entries of d xd / d z in (column, row) order; everything else of [f_x | f_u] is
+        # the identity's 0 or 1.  The expansion kernel writes, the sweep kernels read only these.
+        for wind in (False, True):
+            jac = d[wind][0]
+            pos, k = {}, 0
+            for j in sorted(jac):
+                for i, _ in jac[j]:
+                    pos[(i, j)] = k
+                    k += 1
+            name = "WIND" if wind else "STILL"
+            fh.write(f"constexpr int QUAD_NJ_{name} = {k};   // packed entries per point\n")
+            fh.write(f"// packed position of d xd_i / d z_j, [i][j] row-major (255: structurally zero)\n")
+            fh.write(f"constexpr unsigned char QUAD_JPOS_{name}[12 * 16] = {{\n")
+            for i in range(12):
+                fh.write("    " + ", ".join(str(pos.get((i, j), 255)) for j in range(16)) + ",\n")
+            fh.write("};\n\n")
+            d[wind] = d[wind] + (pos,)
+        fh.write("// column j of the PACKED image: t[pos] = dt * d xd_i / d z_j + (i == j) for the column's nonzero entries (dt = 0: the derivative itself)\n")
+        fh.write("template <bool WIND>\nZM_HD void quad_jac_column_packed(const int j, const QuadAtoms& a, const double dt, double* t) {\n")
+        fh.write("    if constexpr (WIND) {\n")
+        emit_body(fh, d[True][0], pr, "        ", packed=d[True][2])
+        fh.write("    } else {\n")
+        emit_body(fh, d[False][0], pr, "        ", packed=d[False][2])
+        fh.write("    }\n}\n\n")
         fh.write("}  // namespace zm\n")
     for k, v in stats.items():
         print(f"{k[0]} wind={k[1]}: {v[0]} operations before the switch, {v[1]} inside it", file=sys.stderr)

@@ -10,6 +10,8 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 
 // 16 B of zeros: DMA source of the idle lanes, so that every ring slot's padding reads 0.0.
 static __device__ __attribute__((aligned(16))) const double zm_zero_src[2] = {0.0, 0.0};
+// 16 B of ones: a second constant chunk in a slot's padding for kernels whose operands are packed (entries that are not stored are 0 or 1)
+static __device__ __attribute__((aligned(16))) const double zm_one_src[2] = {1.0, 1.0};
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_imm() {

@@ -519,10 +519,15 @@ __global__ __launch_bounds__(64, 2) void ilqr_backward_t16_f64(
 // Slot image of one step (16-B chunks): f_x | f_u | c_x | c_u [| c_xx | c_ux | c_uu unless the Hessians are shared] | zeros.
 namespace zm {
 
-template <int N, int M, bool SHARED, int MODE, int NPAIR = 0>
+// NJP > 0: [f_x | f_u] arrives PACKED -- NJP doubles per step (the structurally nonzero entries of the model's Jacobian, positions in a
+// JacTab; everything else is the identity's 0 or 1, served from two constant chunks in the slot's padding) instead of N (N + M).
+struct JacTab {
+    unsigned char pos[12 * 16];   // packed position of entry (i, j) of [f_x | f_u], 255: not stored
+};
+template <int N, int M, bool SHARED, int MODE, int NPAIR = 0, int NJP = 0>
 struct IlqrDmaGeom {
     static constexpr int KS = N / 4;
-    static constexpr int CFX = N * N / 2, CFU = N * M / 2, CCX = N / 2, CCU = M / 2;
+    static constexpr int CFX = NJP ? NJP / 2 : N * N / 2, CFU = NJP ? 0 : N * M / 2, CCX = N / 2, CCU = M / 2;
     static constexpr int CXX = SHARED ? 0 : N * N / 2, CUX = SHARED ? 0 : N * M / 2, CUU = SHARED ? 0 : M * M / 2;
     static constexpr int CD = (MODE == 1) ? N / 2 : 0;   // MODE 1: the affine term d of the dynamics
     static constexpr int CH = (MODE == 2) ? NPAIR * N / 2 : 0;   // MODE 2: the packed second derivatives H[pair][i] of the step
@@ -534,6 +539,9 @@ struct IlqrDmaGeom {
     static constexpr int OD = OUU + CUU * 16;
     static constexpr int OH = OD + CD * 16;
     static constexpr int OZ = CT * 16;
+    static constexpr int OONE = OZ + 16;   // NJP: a chunk of ones behind the chunk of zeros
+    static_assert(NJP % 2 == 0 && (NJP == 0 || (N == 12 && SHARED)), "packed Jacobians: n = 12, 16-B rows, shared cost Hessians");
+    static_assert(NJP == 0 || SLOT - OZ >= 32, "slot needs a zero and a one chunk");
     static_assert(N % 4 == 0 && N >= 8 && N <= 12 && M == 4, "fast path: all K-step rows live, m = 4");
     static_assert(MODE == 0 || (MODE == 1 && !SHARED) || (MODE == 2 && SHARED && N == 12 && NPAIR > 0 && NPAIR <= ZM_MAX_PAIRS),
                   "iLQR, affine LQR, or DDP with shared cost Hessians and packed second derivatives");
@@ -546,15 +554,15 @@ struct IlqrDmaGeom {
 #ifndef ZM_ILQR_DMA_WAVES
 #define ZM_ILQR_DMA_WAVES 3
 #endif
-template <int N, int M, int D, bool SHARED, int MODE, int NPAIR = 0>
+template <int N, int M, int D, bool SHARED, int MODE, int NPAIR = 0, int NJP = 0>
 __global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVES) void ilqr_backward_dma_f64(
     const double* __restrict__ f_x, const double* __restrict__ f_u, const double* __restrict__ c_x,
     const double* __restrict__ c_u, const double* __restrict__ c_xx, const double* __restrict__ c_ux,
     const double* __restrict__ c_uu, const double* __restrict__ vf_x, const double* __restrict__ vf_xx,
     const double* __restrict__ dvec, const long svx, const long svxx, const int* __restrict__ active,
     double* __restrict__ lout, double* __restrict__ Lout, const int T, const TrajList tl, const double* __restrict__ Hpk,
-    const PairTab ptab) {
-    using G = IlqrDmaGeom<N, M, SHARED, MODE, NPAIR>;
+    const PairTab ptab, const JacTab jtab) {
+    using G = IlqrDmaGeom<N, M, SHARED, MODE, NPAIR, NJP>;
     constexpr int KS = G::KS, NI = G::NI, SLOT = G::SLOT, NP = N;
     constexpr int nn = N * N, nm = N * M, mm = M * M;
     constexpr int SMO = D * SLOT;
@@ -585,10 +593,14 @@ __global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVE
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             int q = i * 64 + lane;
-            const char* src = (const char*)zm_zero_src;
+            const char* src = (NJP && q == G::CT + 1) ? (const char*)zm_one_src : (const char*)zm_zero_src;
             int stride = 0;
             if (q < G::CFX) {
-                src = (const char*)(f_x + last * nn) + q * 16;  stride = nn * 8;
+                if constexpr (NJP != 0) {   // f_x points to the packed images
+                    src = (const char*)(f_x + last * NJP) + q * 16;  stride = NJP * 8;
+                } else {
+                    src = (const char*)(f_x + last * nn) + q * 16;  stride = nn * 8;
+                }
             } else if ((q -= G::CFX) < G::CFU) {
                 src = (const char*)(f_u + last * nm) + q * 16;  stride = nm * 8;
             } else if ((q -= G::CFU) < G::CCX) {
@@ -626,6 +638,13 @@ __global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVE
     // LDS offsets of this lane's operands inside a slot (lanes outside a matrix read the zero padding)
     const int oF = cA ? (G::OFX + (g * N + c) * 8) : cB ? (G::OFU + (g * M + (c - N)) * 8) : G::OZ;
     const int dF = cA ? 4 * N * 8 : cB ? 4 * M * 8 : 0;
+    int oFp[KS];   // NJP: slot offset of F[4s+g][c] -- its packed entry, or the chunk of zeros / ones
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int row = 4 * s + g;
+        const int p = NJP ? (int)jtab.pos[row * 16 + c] : 255;
+        oFp[s] = (p != 255) ? (G::OFX + p * 8) : ((row == c) ? G::OONE : G::OZ);
+    }
     const int ocv = cA ? (G::OCX + c * 8) : cB ? (G::OCU + (c - N) * 8) : G::OZ;
     const int oC = cA ? (G::OXX + (g * N + c) * 8) : G::OZ;       // !SHARED only
     const int dC = cA ? 4 * N * 8 : 0;
@@ -711,7 +730,7 @@ __global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVE
             IlqrStepRegs<KS> d;
             if constexpr (!DIET) {
 #pragma unroll
-                for (int s = 0; s < KS; ++s) d.F[s] = *(const double*)(slot + oF + s * dF);
+                for (int s = 0; s < KS; ++s) d.F[s] = *(const double*)(slot + (NJP ? oFp[s] : oF + s * dF));
                 d.cv = *(const double*)(slot + ocv);
             }
             if constexpr (DIET) {
@@ -757,7 +776,7 @@ __global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVE
                 for (int s = 0; s < KS; ++s) {
                     Vxx[s] = vst[s * 64 + lane];
                     vxr[s] = vst[(KS + s) * 64 + lane];
-                    d.F[s] = *(const double*)(slot + oF + s * dF);
+                    d.F[s] = *(const double*)(slot + (NJP ? oFp[s] : oF + s * dF));
                     d.C[s] = cst[s * 64 + lane];
                 }
                 d.cv = *(const double*)(slot + ocv);
@@ -810,7 +829,7 @@ static int ilqr_backward_dma_dispatch(const double* f_x, const double* f_u, cons
     constexpr int DS = 3, DF = 2;
 #define ZM_LAUNCH_ILQR_DMA(NN, DD, SH)                                                                                     \
     hipLaunchKernelGGL((ilqr_backward_dma_f64<NN, 4, DD, SH, MODE>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, \
-                       vf_x, vf_xx, dvec, svx, svxx, act, l, L, T, tl, (const double*)nullptr, PairTab{})
+                       vf_x, vf_xx, dvec, svx, svxx, act, l, L, T, tl, (const double*)nullptr, PairTab{}, JacTab{})
     if constexpr (MODE == 0) {
         if (n == 12) {
             if (sh) ZM_LAUNCH_ILQR_DMA(12, DS, true); else ZM_LAUNCH_ILQR_DMA(12, DF, false);
@@ -840,7 +859,30 @@ static int ddp_backward_dma_dispatch(const double* f_x, const double* f_u, const
     if (((uintptr_t)f_x | (uintptr_t)f_u | (uintptr_t)c_x | (uintptr_t)c_u | (uintptr_t)Hpk) & 15) return ZM_EUNSUPPORTED;
     const dim3 grid((unsigned)(tl.list ? tl.count : batch)), block(64);
     hipLaunchKernelGGL((ilqr_backward_dma_f64<12, 4, 2, true, 2, 28>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
-                       vf_xx, (const double*)nullptr, svx, 0L, act, l, L, T, tl, Hpk, ptab);
+                       vf_xx, (const double*)nullptr, svx, 0L, act, l, L, T, tl, Hpk, ptab, JacTab{});
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+
+// Solver-internal (ilqr_solve.hip): the iLQR (Hpk == nullptr) or DDP sweep of the listed trajectories with PACKED Jacobians Fp
+// (njp doubles per step: 56 or 60, positions `pos`; written by linearize.hip's packed expansion), shared cost Hessians, n = 12, m = 4.
+int sweep_packed_jacobians(const double* Fp, int njp, const unsigned char* pos, const double* Hpk, const PairTab& ptab, const double* c_x,
+                           const double* c_u, const double* c_xx, const double* c_ux, const double* c_uu, const double* vf_x,
+                           const double* vf_xx, const int* act, double* l, double* L, int64_t batch, int T, hipStream_t st, TrajList tl) {
+    if (((uintptr_t)Fp | (uintptr_t)c_x | (uintptr_t)c_u | (uintptr_t)Hpk) & 15) return ZM_EUNSUPPORTED;
+    if ((njp != 56 && njp != 60) || (Hpk && ptab.n != 28)) return ZM_EUNSUPPORTED;
+    JacTab jt;
+    for (int e = 0; e < 192; ++e) jt.pos[e] = pos[e];
+    const dim3 grid((unsigned)(tl.list ? tl.count : batch)), block(64);
+#define ZM_LAUNCH_PACKED(DD, MODE_, NPAIR_, NJP_)                                                                                   \
+    hipLaunchKernelGGL((ilqr_backward_dma_f64<12, 4, DD, true, MODE_, NPAIR_, NJP_>), grid, block, 0, st, Fp, (const double*)nullptr,  \
+                       c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, (const double*)nullptr, 12L, 0L, act, l, L, T, tl, Hpk, ptab, jt)
+    if (Hpk) {
+        if (njp == 56) ZM_LAUNCH_PACKED(2, 2, 28, 56); else ZM_LAUNCH_PACKED(2, 2, 28, 60);
+    } else {
+        if (njp == 56) ZM_LAUNCH_PACKED(3, 0, 0, 56); else ZM_LAUNCH_PACKED(3, 0, 0, 60);
+    }
+#undef ZM_LAUNCH_PACKED
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }

@@ -12,6 +12,8 @@
 #include <cstdint>
 #include <cstdlib>
 
+#include "models.h"
+#include "quad_derivs_gen.h"
 #include "zm_common.h"
 
 namespace zm {
@@ -79,7 +81,14 @@ static long ilqr_tail_slots(long batch) {
 
 int expand_list(const zm_model_t* model, const zm_quadcost_t* cost, const double* xTraj, const double* uTraj, const int32_t* list,
                 int64_t count, const int32_t* active, double* f_x, double* f_u, double* c_x, double* c_u, double* v_x, int64_t batch,
-                int T, void* stream);
+                int T, void* stream, int packed);
+struct TrajList {
+    const int* list;
+    long count;
+};
+int sweep_packed_jacobians(const double* Fp, int njp, const unsigned char* pos, const double* Hpk, const PairTab& ptab, const double* c_x,
+                           const double* c_u, const double* c_xx, const double* c_ux, const double* c_uu, const double* vf_x,
+                           const double* vf_xx, const int* act, double* l, double* L, int64_t batch, int T, hipStream_t st, TrajList tl);
 bool rollout_all_store_supported(const zm_model_t* model, const zm_quadcost_t* cost, int T);
 int rollout_linesearch_all_store(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0, const double* l, const double* L,
                                  const double* xPrev, const double* uPrev, const double* alphas, const int32_t* list, int64_t count,
@@ -186,6 +195,19 @@ extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* c
     double* f_ux = (need_ux && npairs == 0) ? ws + w.f_ux : nullptr;
     double* f_uu = (need_ux && npairs == 0) ? ws + w.f_uu : nullptr;
     const bool can_all_store = w.tail_slots > 0 && zm::rollout_all_store_supported(model, cost, T);
+    // Packed Jacobians (quadcopter): the expansion writes and the ring sweeps read only the structurally nonzero entries of
+    // [f_x | f_u] -- 448 B (480 with wind) per point instead of 1 536 B.  ZOPT_AMD_JAC=full or ZOPT_AMD_ILQR_PATH=reg: the full matrices.
+    static const bool packed_off = [] {
+        const char* e = getenv("ZOPT_AMD_JAC");
+        const char* r = getenv("ZOPT_AMD_ILQR_PATH");
+        return (e && e[0] == 'f') || (r && r[0] == 'r');
+    }();
+    const bool windy = model->wind_ned[0] != 0.0 || model->wind_ned[1] != 0.0 || model->wind_ned[2] != 0.0;
+    const bool packed = !packed_off && model->kind == ZM_MODEL_QUADCOPTER && model->dt != 0.0 && (((uintptr_t)ws) & 15) == 0 &&
+                        (!ddp || npairs == 28);
+    const int njp = windy ? ((zm::QUAD_NJ_WIND + 1) & ~1) : ((zm::QUAD_NJ_STILL + 1) & ~1);
+    const unsigned char* jpos = windy ? zm::QUAD_JPOS_WIND : zm::QUAD_JPOS_STILL;
+    const zm::PairTab ptab = zm::model_pair_table(model->kind);
     int32_t* widx = (int32_t*)(ws + w.idx);
     int it = 0;
     int64_t count = batch;
@@ -203,9 +225,18 @@ extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* c
         }
         // expansions along the current trajectories: [f_x | f_u], c_x, c_u, v_x in one launch                  (:304-313)
         rc = zm::expand_list(model, cost, xTraj, uTraj, list, count, active, ws + w.f_x, ws + w.f_u, ws + w.c_x, ws + w.c_u,
-                             ws + w.v_x, batch, T, st);
+                             ws + w.v_x, batch, T, st, packed ? 1 : 0);
         if (rc) return rc;
-        if (ddp && npairs > 0) {
+        if (packed) {
+            if (ddp) {
+                rc = zm_quadratic_dynamics_pairs_list_f64(model, xTraj, uTraj, list, count, active, ws + w.f_xx, batch, T, st);
+                if (rc) return rc;
+            }
+            rc = zm::sweep_packed_jacobians(ws + w.f_x, njp, jpos, ddp ? ws + w.f_xx : nullptr, ptab, ws + w.c_x, ws + w.c_u, ws + w.c_xx,
+                                            ws + w.c_ux, ws + w.c_uu, ws + w.v_x, ws + w.v_xx, (const int*)active, ws + w.l, L, batch, T,
+                                            (hipStream_t)st, zm::TrajList{(const int*)list, (long)count});
+            if (rc == ZM_EUNSUPPORTED) return zm::set_error(ZM_EUNSUPPORTED, "zm_ilqr_solve_f64: packed sweep refused its operands");
+        } else if (ddp && npairs > 0) {
             // packed second derivatives: 28 x 12 doubles per point for the quadcopter instead of the zero-filled (n,n,n) tensors
             // (2.7 KB instead of 13.8 KB written by the expansion and read back by the sweep, same arithmetic)
             rc = zm_quadratic_dynamics_pairs_list_f64(model, xTraj, uTraj, list, count, active, ws + w.f_xx, batch, T, st);

@@ -48,7 +48,10 @@ struct ExpandCost {
 constexpr int LIN_WAVES = 4;
 // WIND (quadcopter): constant NED wind -- the still-air closed forms are less than half as long; carrying both behind a run-time test
 // cost the kernel 40 registers (130 against 92) and with them two of its five waves per SIMD
-template <bool COST, bool QUAD, bool WIND = false>
+// PACKED (quadcopter, dt != 0): `f_x` receives the packed image of [f_x | f_u] -- the structurally nonzero entries of d xd / d z only
+// (quad_derivs_gen.h: 56 per point in still air, 59 (+1 pad) with wind; everything else is the identity's 0 or 1) -- 448 B per point
+// instead of 1 536 B; `f_u` is not written.  The solvers' sweeps read this form (ilqr_backward_dma_f64<..., NJP>).
+template <bool COST, bool QUAD, bool WIND = false, bool PACKED = false>
 __global__ __launch_bounds__(64 * LIN_WAVES, 3) void linearize_dynamics_kernel(const zm_model_t md, const double* __restrict__ xTraj,
                                                                 const double* __restrict__ uTraj,
                                                                 const int* __restrict__ active, double* __restrict__ f,
@@ -124,6 +127,17 @@ __global__ __launch_bounds__(64 * LIN_WAVES, 3) void linearize_dynamics_kernel(c
                 }
                 ec.c_u[pt * m + ju] = g;
             }
+        }
+        if constexpr (PACKED) {
+            static_assert(QUAD, "packed Jacobians: the quadcopter's closed forms");
+            constexpr int NJ = WIND ? QUAD_NJ_WIND : QUAD_NJ_STILL, NJP = (NJ + 1) & ~1;
+            const QuadAtoms a = quad_atoms(md, xv, uv);
+            if (NJP != NJ && j == 0) tile[q][NJP - 1] = 0.0;
+            quad_jac_column_packed<WIND>(j, a, md.dt, tile[q]);
+            wave_lds_sync();
+            double* op = f_x + pt * NJP;
+            for (int e = j; e < NJP; e += 16) op[e] = tile[q][e];
+            return;
         }
         double col[MAXN];                                      // column j of [f_x | f_u] (lanes j >= n + m: unused)
         if constexpr (QUAD) {
@@ -503,7 +517,7 @@ extern "C" int zm_linearize_dynamics_list_f64(const zm_model_t* model, const dou
 namespace zm {
 int expand_list(const zm_model_t* model, const zm_quadcost_t* cost, const double* xTraj, const double* uTraj, const int32_t* list,
                 int64_t count, const int32_t* active, double* f_x, double* f_u, double* c_x, double* c_u, double* v_x, int64_t batch,
-                int T, void* stream) {
+                int T, void* stream, int packed) {
     if (batch == 0 || count == 0) return ZM_OK;
     zm_model_t md;
     int rc = zm_check_model(model, md, "expand_list");
@@ -519,7 +533,14 @@ int expand_list(const zm_model_t* model, const zm_quadcost_t* cost, const double
     const dim3 grid((unsigned)((ngrp + GPB - 1) / GPB)), block(64 * LIN_WAVES);
     const ExpandCost ec{*cost, c_x, c_u, v_x};
     const bool windy = md.wind_ned[0] != 0.0 || md.wind_ned[1] != 0.0 || md.wind_ned[2] != 0.0;
-    if (quad && windy)
+    if (packed && (!quad || md.dt == 0.0)) return set_error(ZM_EUNSUPPORTED, "expand_list: packed Jacobians need the quadcopter with dt != 0");
+    if (packed && windy)
+        hipLaunchKernelGGL((linearize_dynamics_kernel<true, true, true, true>), grid, block, 0, (hipStream_t)stream, md, xTraj, uTraj,
+                           (const int*)active, (double*)nullptr, f_x, f_u, (long)batch, T, (const int*)list, (long)count, ec);
+    else if (packed)
+        hipLaunchKernelGGL((linearize_dynamics_kernel<true, true, false, true>), grid, block, 0, (hipStream_t)stream, md, xTraj, uTraj,
+                           (const int*)active, (double*)nullptr, f_x, f_u, (long)batch, T, (const int*)list, (long)count, ec);
+    else if (quad && windy)
         hipLaunchKernelGGL((linearize_dynamics_kernel<true, true, true>), grid, block, 0, (hipStream_t)stream, md, xTraj, uTraj,
                            (const int*)active, (double*)nullptr, f_x, f_u, (long)batch, T, (const int*)list, (long)count, ec);
     else if (quad)
