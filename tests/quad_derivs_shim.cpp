@@ -50,3 +50,17 @@ extern "C" int quad_jacobian_packed(const double* x, const double* u, const doub
     for (int e = 0; e < 192; ++e) pos[e] = p[e];
     return still_air ? zm::QUAD_NJ_STILL : zm::QUAD_NJ_WIND;
 }
+
+// the sparse image of the second derivatives (quad_hess_pair2_packed) and the dense index table that goes with it
+extern "C" int quad_hessian_sparse(const double* x, const double* u, const double* w, int still_air, double dt, double* t /* >= 86 */,
+                                   unsigned short* dense /* >= 86 */) {
+    const zm::QuadAtoms a = atoms(x, u, w);
+    for (int j = 0; j < 14; ++j) {
+        if (still_air) zm::quad_hess_pair2_packed<false>(j, a, dt, t);
+        else zm::quad_hess_pair2_packed<true>(j, a, dt, t);
+    }
+    const int nh = still_air ? zm::QUAD_NH_STILL : zm::QUAD_NH_WIND;
+    const unsigned short* p = still_air ? zm::QUAD_HDENSE_STILL : zm::QUAD_HDENSE_WIND;
+    for (int e = 0; e < nh; ++e) dense[e] = p[e];
+    return nh;
+}

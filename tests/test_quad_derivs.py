@@ -29,6 +29,8 @@ def shim(tmp_path_factory):
     lib.quad_hessian_pairs.argtypes = [dp, dp, dp, ctypes.c_int, ctypes.c_int, dp]
     lib.quad_jacobian_packed.argtypes = [dp, dp, dp, ctypes.c_int, ctypes.c_double, dp, ctypes.POINTER(ctypes.c_ubyte)]
     lib.quad_jacobian_packed.restype = ctypes.c_int
+    lib.quad_hessian_sparse.argtypes = [dp, dp, dp, ctypes.c_int, ctypes.c_double, dp, ctypes.POINTER(ctypes.c_ushort)]
+    lib.quad_hessian_sparse.restype = ctypes.c_int
     return lib
 
 
@@ -125,6 +127,24 @@ def test_packed_jacobian_image_rebuilds_the_full_matrices(shim, wind):
         ref = np.hstack([np.eye(12), np.zeros((12, 4))]) + dt * _complex_step_jacobian(x, u, w)
         assert np.max(np.abs(F - ref)) <= 1e-13 * max(1.0, np.abs(ref).max())
         assert np.all((ref != np.hstack([np.eye(12), np.zeros((12, 4))])) <= (pos != 255))     # nothing outside the packed set moves
+
+
+@pytest.mark.parametrize("wind", [(0.0, 0.0, 0.0), (3.0, 1.0, -0.5)])
+def test_sparse_second_derivative_image_rebuilds_the_dense_rows(shim, wind):
+    """quad_hess_pair2_packed + QUAD_HDENSE_*: the packed entries scattered to pair * 12 + i, zeros elsewhere, are dt times the dense
+    rows of quad_hess_pair (the form the DDP expansion writes and the sweep scatters into its LDS image)"""
+    w, dt = np.array(wind), 0.1
+    still = 0 if np.any(w) else 1
+    for x, u in _points(6, 6):
+        t = np.full(96, np.nan)
+        dense = np.zeros(96, dtype=np.uint16)
+        nh = shim.quad_hessian_sparse(_p(x), _p(u), _p(w), still, dt, _p(t), dense.ctypes.data_as(ctypes.POINTER(ctypes.c_ushort)))
+        assert nh == (69 if still else 85) and len(set(dense[:nh].tolist())) == nh and np.all(np.isfinite(t[:nh]))
+        H = np.zeros((len(PAIRS), 12))
+        shim.quad_hessian_pairs(_p(x), _p(u), _p(w), still, len(PAIRS), _p(H))
+        R = np.zeros(len(PAIRS) * 12)
+        R[dense[:nh]] = t[:nh]
+        assert np.array_equal(R.reshape(len(PAIRS), 12), dt * H)          # same expressions, same bits; and nothing nonzero is left out
 
 
 def test_header_is_what_the_generator_writes(tmp_path):

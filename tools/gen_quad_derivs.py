@@ -88,7 +88,7 @@ class Printer(C99CodePrinter):
         return repr(float(r))
 
 
-def emit_body(fh, table, pr, ind, packed=None):
+def emit_body(fh, table, pr, ind, packed=None, delta=True):
     """table: {case -> [(i, expr)]}.  One CSE over everything; a temporary that serves several cases is computed by every lane before
     the switch, one that serves a single case inside it.  packed = {(i, case) -> position}: instead of o[i] = expr the case writes
     t[position] = dt * expr + (i == case) -- the packed image of column `case` of [f_x | f_u] = I + dt d xd / d z."""
@@ -121,7 +121,10 @@ def emit_body(fh, table, pr, ind, packed=None):
             if cc == c and packed is None:
                 fh.write(f"{ind}        o[{i}] = {pr.doprint(o)};\n")
             elif cc == c:
-                fh.write(f"{ind}        t[{packed[(i, c)]}] = (dt == 0.0) ? ({pr.doprint(o)}) : __builtin_fma(dt, {pr.doprint(o)}, {1.0 if i == c else 0.0});\n")
+                if delta:
+                    fh.write(f"{ind}        t[{packed[(i, c)]}] = (dt == 0.0) ? ({pr.doprint(o)}) : __builtin_fma(dt, {pr.doprint(o)}, {1.0 if i == c else 0.0});\n")
+                else:   # (the kernels' own form: o = (dt == 0) ? h : dt * h)
+                    fh.write(f"{ind}        t[{packed[(i, c)]}] = (dt == 0.0) ? ({pr.doprint(o)}) : dt * ({pr.doprint(o)});\n")
         fh.write(f"{ind}    }} break;\n")
     fh.write(f"{ind}    default: break;\n{ind}}}\n")
     shared_ops = sum(sp.count_ops(e) for t, e in temps if len(use[t]) > 1)
@@ -210,6 +213,42 @@ def main():
         emit_body(fh, d[True][0], pr, "        ", packed=d[True][2])
         fh.write("    } else {\n")
         emit_body(fh, d[False][0], pr, "        ", packed=d[False][2])
+        fh.write("    }\n}\n\n")
+        # sparse second derivatives: of the 28 x 12 entries H[pair][i] only NH are structurally nonzero; the expansion writes those, the
+        # DDP sweep scatters them into its dense LDS image (whose other entries stay zero)
+        for wind in (False, True):
+            hes = d[wind][1]
+            hpos, k = {}, 0
+            for pr_ in sorted(hes):
+                for i, _ in hes[pr_]:
+                    hpos[(i, pr_)] = k
+                    k += 1
+            name = "WIND" if wind else "STILL"
+            fh.write(f"constexpr int QUAD_NH_{name} = {k};   // structurally nonzero second derivatives per point\n")
+            fh.write(f"// dense index pair * 12 + i of packed entry k\n")
+            fh.write(f"constexpr unsigned short QUAD_HDENSE_{name}[{k}] = {{\n    "
+                     + ", ".join(str(pr_ * 12 + i) for (i, pr_), _ in sorted(hpos.items(), key=lambda kv: kv[1])) + ",\n};\n\n")
+            d[wind] = d[wind] + (hpos,)
+
+        def two_pairs_packed(hes, hpos):   # case j: pairs 2j and 2j+1; "row" index = packed position, "column" = the case
+            tab, pk = {}, {}
+            for j in range((len(PAIRS) + 1) // 2):
+                tab[j] = []
+                for pr_ in (2 * j, 2 * j + 1):
+                    for i, e in hes.get(pr_, []):
+                        tab[j].append((hpos[(i, pr_)], e))
+                        pk[(hpos[(i, pr_)], j)] = hpos[(i, pr_)]
+            return tab, pk
+
+        fh.write("// the SPARSE image of the second derivatives: case j writes t[k] = dt * d2 xd_i (dt = 0: the derivative itself) for the nonzero\n"
+                 "// entries of pairs 2j and 2j+1 at their packed positions k (QUAD_HDENSE_*)\n")
+        fh.write("template <bool WIND>\nZM_HD void quad_hess_pair2_packed(const int j, const QuadAtoms& a, const double dt, double* t) {\n")
+        fh.write("    if constexpr (WIND) {\n")
+        tab, pk = two_pairs_packed(d[True][1], d[True][3])
+        emit_body(fh, tab, pr, "        ", packed=pk, delta=False)
+        fh.write("    } else {\n")
+        tab, pk = two_pairs_packed(d[False][1], d[False][3])
+        emit_body(fh, tab, pr, "        ", packed=pk, delta=False)
         fh.write("    }\n}\n\n")
         fh.write("}  // namespace zm\n")
     for k, v in stats.items():

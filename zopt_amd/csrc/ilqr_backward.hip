@@ -524,13 +524,19 @@ namespace zm {
 struct JacTab {
     unsigned char pos[12 * 16];   // packed position of entry (i, j) of [f_x | f_u], 255: not stored
 };
-template <int N, int M, bool SHARED, int MODE, int NPAIR = 0, int NJP = 0>
+// NHS > 0 (MODE 2): the second derivatives arrive SPARSE -- NHS doubles per step (their structurally nonzero entries, dense positions in
+// an HTab), scattered every step into a dense [NPAIR][N] image that lives once in LDS (its other entries stay zero).
+struct HTab {
+    unsigned short dense[96];   // dense index pair * N + i of sparse entry k
+    int n;                      // entries (<= 96)
+};
+template <int N, int M, bool SHARED, int MODE, int NPAIR = 0, int NJP = 0, int NHS = 0>
 struct IlqrDmaGeom {
     static constexpr int KS = N / 4;
     static constexpr int CFX = NJP ? NJP / 2 : N * N / 2, CFU = NJP ? 0 : N * M / 2, CCX = N / 2, CCU = M / 2;
     static constexpr int CXX = SHARED ? 0 : N * N / 2, CUX = SHARED ? 0 : N * M / 2, CUU = SHARED ? 0 : M * M / 2;
     static constexpr int CD = (MODE == 1) ? N / 2 : 0;   // MODE 1: the affine term d of the dynamics
-    static constexpr int CH = (MODE == 2) ? NPAIR * N / 2 : 0;   // MODE 2: the packed second derivatives H[pair][i] of the step
+    static constexpr int CH = (MODE == 2) ? (NHS ? NHS / 2 : NPAIR * N / 2) : 0;   // MODE 2: the second derivatives H[pair][i] of the step
     static constexpr int CT = CFX + CFU + CCX + CCU + CXX + CUX + CUU + CD + CH;
     static constexpr int NI = (CT + 63) / 64;
     static constexpr int SLOT = NI * 1024;
@@ -554,15 +560,16 @@ struct IlqrDmaGeom {
 #ifndef ZM_ILQR_DMA_WAVES
 #define ZM_ILQR_DMA_WAVES 3
 #endif
-template <int N, int M, int D, bool SHARED, int MODE, int NPAIR = 0, int NJP = 0>
+template <int N, int M, int D, bool SHARED, int MODE, int NPAIR = 0, int NJP = 0, int NHS = 0>
 __global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVES) void ilqr_backward_dma_f64(
     const double* __restrict__ f_x, const double* __restrict__ f_u, const double* __restrict__ c_x,
     const double* __restrict__ c_u, const double* __restrict__ c_xx, const double* __restrict__ c_ux,
     const double* __restrict__ c_uu, const double* __restrict__ vf_x, const double* __restrict__ vf_xx,
     const double* __restrict__ dvec, const long svx, const long svxx, const int* __restrict__ active,
     double* __restrict__ lout, double* __restrict__ Lout, const int T, const TrajList tl, const double* __restrict__ Hpk,
-    const PairTab ptab, const JacTab jtab) {
-    using G = IlqrDmaGeom<N, M, SHARED, MODE, NPAIR, NJP>;
+    const PairTab ptab, const JacTab jtab, const HTab htab) {
+    using G = IlqrDmaGeom<N, M, SHARED, MODE, NPAIR, NJP, NHS>;
+    static_assert(NHS % 2 == 0 && NHS <= 96 && (NHS == 0 || MODE == 2), "sparse second derivatives: DDP mode, 16-B rows");
     constexpr int KS = G::KS, NI = G::NI, SLOT = G::SLOT, NP = N;
     constexpr int nn = N * N, nm = N * M, mm = M * M;
     constexpr int SMO = D * SLOT;
@@ -573,12 +580,14 @@ __global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVE
 #ifndef ZM_DDP_LDS_PAD   // occupancy experiments: extra bytes of LDS per wave in MODE 2
 #define ZM_DDP_LDS_PAD 0
 #endif
-    __shared__ __attribute__((aligned(16))) char lds[SMO + ILQR_LDS_DOUBLES * 8 + (MODE == 2 ? NS_LDS_DOUBLES * 8 + ZM_DDP_LDS_PAD : 0) + (XST + VST + CST) * 8];
+    constexpr int HDN = NHS ? NPAIR * N : 0;   // dense image of the sparse second derivatives
+    __shared__ __attribute__((aligned(16))) char lds[SMO + ILQR_LDS_DOUBLES * 8 + (MODE == 2 ? NS_LDS_DOUBLES * 8 + ZM_DDP_LDS_PAD : 0) + (XST + VST + CST + HDN) * 8];
     double* sm = (double*)(lds + SMO);
     double* jA = (double*)(lds + SMO + ILQR_LDS_DOUBLES * 8);   // MODE 2: transpose buffers of the sign iteration (ns16.h)
     double* xst = jA + NS_LDS_DOUBLES;
     double* vst = xst + XST;
     double* cst = vst + VST;
+    double* hd = cst + CST;
     const int lane = threadIdx.x;
     const long traj = tl.list ? (long)tl.list[blockIdx.x] : (long)blockIdx.x;
     if (active && active[traj] == 0) return;   // whole wave leaves: this trajectory keeps its previous policy
@@ -609,7 +618,8 @@ __global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVE
                 src = (const char*)(c_u + last * M) + q * 16;   stride = M * 8;
             } else if constexpr (MODE == 2) {
                 if ((q -= G::CCU) < G::CH) {
-                    src = (const char*)(Hpk + last * (long)(NPAIR * N)) + q * 16;  stride = NPAIR * N * 8;
+                    constexpr int HROW = NHS ? NHS : NPAIR * N;   // doubles per step in HBM
+                    src = (const char*)(Hpk + last * (long)HROW) + q * 16;  stride = HROW * 8;
                 }
             } else if constexpr (!SHARED) {
                 if ((q -= G::CCU) < G::CXX) {
@@ -673,7 +683,7 @@ __global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVE
             int pidx = -1;
             for (int q = 0; q < NPAIR; ++q) pidx = (ptab.ab[q] == (unsigned char)(lo * 16 + hi)) ? q : pidx;
             zok[r] = pidx >= 0;
-            oH[r] = G::OH + (pidx >= 0 ? pidx : 0) * (N * 8);
+            oH[r] = (NHS ? 0 : G::OH) + (pidx >= 0 ? pidx : 0) * (N * 8);   // NHS: relative to the dense image, else to the slot
             a.zlive[r] = (row == c);   // n + m = 16: every tile index is a live (state or control) index
         }
     }
@@ -716,6 +726,12 @@ __global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVE
         for (int s = 0; s < KS; ++s) cst[s * 64 + lane] = Csh[s];
         cst[KS * 64 + lane] = Cush;
     }
+    int hdst0 = 0, hdst1 = 0;   // NHS: dense positions of sparse entries lane, lane + 64
+    if constexpr (NHS != 0) {
+        for (int e = lane; e < HDN; e += 64) hd[e] = 0.0;
+        hdst0 = (lane < htab.n) ? (int)htab.dense[lane] : -1;
+        hdst1 = (lane + 64 < htab.n) ? (int)htab.dense[(lane + 64) % 96] : -1;
+    }
     ilqr_lds_sync();
 
 #pragma unroll
@@ -750,6 +766,13 @@ __global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVE
                 for (int s = 0; s < KS; ++s) d.dr[s] = *(const double*)(slot + G::OD + (4 * s + g) * 8);
             }
             d4 zin = zero4();
+            if constexpr (NHS != 0) {   // this step's nonzero second derivatives into the dense image
+                const double* hs = (const double*)(slot + G::OH);
+                const double h0 = hs[lane], h1 = hs[(lane + 64 < NHS) ? lane + 64 : 0];
+                if (hdst0 >= 0) hd[hdst0] = h0;
+                if (hdst1 >= 0) hd[hdst1] = h1;
+                ilqr_lds_sync();
+            }
             if constexpr (DIET) {
                 // (see below) the projection first, with as little as possible alive: V, v wait in LDS, the step's operands are
                 // read from the ring afterwards -- the slot is refilled one projection later than otherwise, still a step ahead
@@ -758,7 +781,7 @@ __global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVE
                 for (int i = 0; i < N; ++i) vx[i] = sm[80 + i];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double* h = (const double*)(slot + oH[r]);
+                    const double* h = NHS ? (const double*)((const char*)hd + oH[r]) : (const double*)(slot + oH[r]);
                     double z = 0.0;
 #pragma unroll
                     for (int i = 0; i < N; ++i) z = __builtin_fma(vx[i], h[i], z);
@@ -789,7 +812,7 @@ __global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVE
                 for (int i = 0; i < N; ++i) vx[i] = sm[80 + i];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double* h = (const double*)(slot + oH[r]);
+                    const double* h = NHS ? (const double*)((const char*)hd + oH[r]) : (const double*)(slot + oH[r]);
                     double z = 0.0;
 #pragma unroll
                     for (int i = 0; i < N; ++i) z = __builtin_fma(vx[i], h[i], z);
@@ -829,7 +852,7 @@ static int ilqr_backward_dma_dispatch(const double* f_x, const double* f_u, cons
     constexpr int DS = 3, DF = 2;
 #define ZM_LAUNCH_ILQR_DMA(NN, DD, SH)                                                                                     \
     hipLaunchKernelGGL((ilqr_backward_dma_f64<NN, 4, DD, SH, MODE>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, \
-                       vf_x, vf_xx, dvec, svx, svxx, act, l, L, T, tl, (const double*)nullptr, PairTab{}, JacTab{})
+                       vf_x, vf_xx, dvec, svx, svxx, act, l, L, T, tl, (const double*)nullptr, PairTab{}, JacTab{}, HTab{})
     if constexpr (MODE == 0) {
         if (n == 12) {
             if (sh) ZM_LAUNCH_ILQR_DMA(12, DS, true); else ZM_LAUNCH_ILQR_DMA(12, DF, false);
@@ -859,28 +882,36 @@ static int ddp_backward_dma_dispatch(const double* f_x, const double* f_u, const
     if (((uintptr_t)f_x | (uintptr_t)f_u | (uintptr_t)c_x | (uintptr_t)c_u | (uintptr_t)Hpk) & 15) return ZM_EUNSUPPORTED;
     const dim3 grid((unsigned)(tl.list ? tl.count : batch)), block(64);
     hipLaunchKernelGGL((ilqr_backward_dma_f64<12, 4, 2, true, 2, 28>), grid, block, 0, st, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x,
-                       vf_xx, (const double*)nullptr, svx, 0L, act, l, L, T, tl, Hpk, ptab, JacTab{});
+                       vf_xx, (const double*)nullptr, svx, 0L, act, l, L, T, tl, Hpk, ptab, JacTab{}, HTab{});
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }
 
 // Solver-internal (ilqr_solve.hip): the iLQR (Hpk == nullptr) or DDP sweep of the listed trajectories with PACKED Jacobians Fp
 // (njp doubles per step: 56 or 60, positions `pos`; written by linearize.hip's packed expansion), shared cost Hessians, n = 12, m = 4.
+// nhs > 0: Hpk holds the SPARSE second derivatives, nhs doubles per step (70 or 86), dense positions `hdense` (nh of them).
 int sweep_packed_jacobians(const double* Fp, int njp, const unsigned char* pos, const double* Hpk, const PairTab& ptab, const double* c_x,
                            const double* c_u, const double* c_xx, const double* c_ux, const double* c_uu, const double* vf_x,
-                           const double* vf_xx, const int* act, double* l, double* L, int64_t batch, int T, hipStream_t st, TrajList tl) {
+                           const double* vf_xx, const int* act, double* l, double* L, int64_t batch, int T, hipStream_t st, TrajList tl,
+                           int nhs, const unsigned short* hdense, int nh) {
     if (((uintptr_t)Fp | (uintptr_t)c_x | (uintptr_t)c_u | (uintptr_t)Hpk) & 15) return ZM_EUNSUPPORTED;
     if ((njp != 56 && njp != 60) || (Hpk && ptab.n != 28)) return ZM_EUNSUPPORTED;
+    if (nhs && !(Hpk && ((njp == 56 && nhs == 70) || (njp == 60 && nhs == 86)) && hdense && nh > 0 && nh <= nhs)) return ZM_EUNSUPPORTED;
     JacTab jt;
     for (int e = 0; e < 192; ++e) jt.pos[e] = pos[e];
+    HTab ht{};
+    for (int e = 0; e < nh && nhs; ++e) ht.dense[e] = hdense[e];
+    ht.n = nhs ? nh : 0;
     const dim3 grid((unsigned)(tl.list ? tl.count : batch)), block(64);
-#define ZM_LAUNCH_PACKED(DD, MODE_, NPAIR_, NJP_)                                                                                   \
-    hipLaunchKernelGGL((ilqr_backward_dma_f64<12, 4, DD, true, MODE_, NPAIR_, NJP_>), grid, block, 0, st, Fp, (const double*)nullptr,  \
-                       c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, (const double*)nullptr, 12L, 0L, act, l, L, T, tl, Hpk, ptab, jt)
-    if (Hpk) {
-        if (njp == 56) ZM_LAUNCH_PACKED(2, 2, 28, 56); else ZM_LAUNCH_PACKED(2, 2, 28, 60);
+#define ZM_LAUNCH_PACKED(DD, MODE_, NPAIR_, NJP_, NHS_)                                                                               \
+    hipLaunchKernelGGL((ilqr_backward_dma_f64<12, 4, DD, true, MODE_, NPAIR_, NJP_, NHS_>), grid, block, 0, st, Fp, (const double*)nullptr,  \
+                       c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, (const double*)nullptr, 12L, 0L, act, l, L, T, tl, Hpk, ptab, jt, ht)
+    if (Hpk && nhs) {
+        if (njp == 56) ZM_LAUNCH_PACKED(2, 2, 28, 56, 70); else ZM_LAUNCH_PACKED(2, 2, 28, 60, 86);
+    } else if (Hpk) {
+        if (njp == 56) ZM_LAUNCH_PACKED(2, 2, 28, 56, 0); else ZM_LAUNCH_PACKED(2, 2, 28, 60, 0);
     } else {
-        if (njp == 56) ZM_LAUNCH_PACKED(3, 0, 0, 56); else ZM_LAUNCH_PACKED(3, 0, 0, 60);
+        if (njp == 56) ZM_LAUNCH_PACKED(3, 0, 0, 56, 0); else ZM_LAUNCH_PACKED(3, 0, 0, 60, 0);
     }
 #undef ZM_LAUNCH_PACKED
     ZM_HIP_CHECK(hipGetLastError());

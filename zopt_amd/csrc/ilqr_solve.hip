@@ -88,7 +88,10 @@ struct TrajList {
 };
 int sweep_packed_jacobians(const double* Fp, int njp, const unsigned char* pos, const double* Hpk, const PairTab& ptab, const double* c_x,
                            const double* c_u, const double* c_xx, const double* c_ux, const double* c_uu, const double* vf_x,
-                           const double* vf_xx, const int* act, double* l, double* L, int64_t batch, int T, hipStream_t st, TrajList tl);
+                           const double* vf_xx, const int* act, double* l, double* L, int64_t batch, int T, hipStream_t st, TrajList tl,
+                           int nhs, const unsigned short* hdense, int nh);
+int quad_hessian_sparse_list(const zm_model_t* model, const double* xTraj, const double* uTraj, const int32_t* list, int64_t count,
+                             const int32_t* active, double* Hs, int64_t batch, int T, void* stream);
 bool rollout_all_store_supported(const zm_model_t* model, const zm_quadcost_t* cost, int T);
 int rollout_linesearch_all_store(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0, const double* l, const double* L,
                                  const double* xPrev, const double* uPrev, const double* alphas, const int32_t* list, int64_t count,
@@ -208,6 +211,15 @@ extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* c
     const int njp = windy ? ((zm::QUAD_NJ_WIND + 1) & ~1) : ((zm::QUAD_NJ_STILL + 1) & ~1);
     const unsigned char* jpos = windy ? zm::QUAD_JPOS_WIND : zm::QUAD_JPOS_STILL;
     const zm::PairTab ptab = zm::model_pair_table(model->kind);
+    // ... and the DDP path's second derivatives SPARSE (69 / 85 structurally nonzero entries of the 28 x 12 per point; ZOPT_AMD_HES=dense:
+    // the dense pair rows)
+    static const bool sparse_off = [] {
+        const char* e = getenv("ZOPT_AMD_HES");
+        return e && e[0] == 'd';
+    }();
+    const bool sparse_h = packed && ddp && !sparse_off;
+    const int nh = windy ? zm::QUAD_NH_WIND : zm::QUAD_NH_STILL, nhs = (nh + 1) & ~1;
+    const unsigned short* hdense = windy ? zm::QUAD_HDENSE_WIND : zm::QUAD_HDENSE_STILL;
     int32_t* widx = (int32_t*)(ws + w.idx);
     int it = 0;
     int64_t count = batch;
@@ -228,13 +240,16 @@ extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* c
                              ws + w.v_x, batch, T, st, packed ? 1 : 0);
         if (rc) return rc;
         if (packed) {
-            if (ddp) {
+            if (sparse_h) {
+                rc = zm::quad_hessian_sparse_list(model, xTraj, uTraj, list, count, active, ws + w.f_xx, batch, T, st);
+                if (rc) return rc;
+            } else if (ddp) {
                 rc = zm_quadratic_dynamics_pairs_list_f64(model, xTraj, uTraj, list, count, active, ws + w.f_xx, batch, T, st);
                 if (rc) return rc;
             }
             rc = zm::sweep_packed_jacobians(ws + w.f_x, njp, jpos, ddp ? ws + w.f_xx : nullptr, ptab, ws + w.c_x, ws + w.c_u, ws + w.c_xx,
                                             ws + w.c_ux, ws + w.c_uu, ws + w.v_x, ws + w.v_xx, (const int*)active, ws + w.l, L, batch, T,
-                                            (hipStream_t)st, zm::TrajList{(const int*)list, (long)count});
+                                            (hipStream_t)st, zm::TrajList{(const int*)list, (long)count}, sparse_h ? nhs : 0, hdense, nh);
             if (rc == ZM_EUNSUPPORTED) return zm::set_error(ZM_EUNSUPPORTED, "zm_ilqr_solve_f64: packed sweep refused its operands");
         } else if (ddp && npairs > 0) {
             // packed second derivatives: 28 x 12 doubles per point for the quadcopter instead of the zero-filled (n,n,n) tensors

@@ -336,7 +336,9 @@ __global__ __launch_bounds__(64 * LIN_WAVES) void quadratic_dynamics_pairs_kerne
 // closed forms of pairs 2j and 2j+1 (quad_hess_pair2), the 28 x 12 image of the point is gathered in LDS and leaves as whole lines.
 // Halves the instructions per point of quadratic_dynamics_pairs_kernel (whose 32-lane groups leave every second SIMD lane group idle
 // through the shared part).
-template <bool WIND>
+// SPARSE: only the structurally nonzero entries leave (QUAD_NH_*: 69 in still air, 85 with wind, padded to an even count; positions
+// QUAD_HDENSE_*) -- 560 B per point instead of 2 688 B; the DDP ring sweep scatters them into its dense LDS image.
+template <bool WIND, bool SPARSE = false>
 __global__ __launch_bounds__(64 * LIN_WAVES) void quad_hessian_pairs16_kernel(const zm_model_t md, const double* __restrict__ xTraj,
                                                                               const double* __restrict__ uTraj,
                                                                               const int* __restrict__ active, double* __restrict__ H,
@@ -356,6 +358,15 @@ __global__ __launch_bounds__(64 * LIN_WAVES) void quad_hessian_pairs16_kernel(co
     const double* uk = uTraj + pt * 4;
     const QuadAtoms at = quad_atoms(md, xk, uk);
     if (active && active[traj] == 0) return;
+    if constexpr (SPARSE) {
+        constexpr int NH = WIND ? QUAD_NH_WIND : QUAD_NH_STILL, NHP = (NH + 1) & ~1;
+        if (NHP != NH && j == 15) tile[q][NHP - 1] = 0.0;
+        quad_hess_pair2_packed<WIND>(j, at, md.dt, tile[q]);
+        wave_lds_sync();
+        double* out = H + pt * NHP;
+        for (int e = j; e < NHP; e += 16) out[e] = tile[q][e];
+        return;
+    }
     double o[24];
     quad_hess_pair2<WIND>(j, at, o);
     if (j < NPR / 2) {
@@ -664,6 +675,30 @@ extern "C" int zm_quadratic_dynamics_pairs_list_f64(const zm_model_t* model, con
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }
+
+// Solver-internal (ilqr_solve.hip): the quadcopter's second derivatives in SPARSE form for the listed trajectories
+namespace zm {
+int quad_hessian_sparse_list(const zm_model_t* model, const double* xTraj, const double* uTraj, const int32_t* list, int64_t count,
+                             const int32_t* active, double* Hs, int64_t batch, int T, void* stream) {
+    if (batch == 0 || count == 0) return ZM_OK;
+    zm_model_t md;
+    int rc = zm_check_model(model, md, "quad_hessian_sparse_list");
+    if (rc) return rc;
+    if (md.kind != ZM_MODEL_QUADCOPTER || !xTraj || !uTraj || !list || !Hs || T < 1 || count < 0 || count > batch)
+        return set_error(ZM_EINVAL, "quad_hessian_sparse_list: bad argument");
+    constexpr int PPB16 = 4 * LIN_WAVES;
+    const long npts = (long)count * T;
+    const dim3 grid16((unsigned)((npts + PPB16 - 1) / PPB16)), block16(64 * LIN_WAVES);
+    if (md.wind_ned[0] != 0.0 || md.wind_ned[1] != 0.0 || md.wind_ned[2] != 0.0)
+        hipLaunchKernelGGL((quad_hessian_pairs16_kernel<true, true>), grid16, block16, 0, (hipStream_t)stream, md, xTraj, uTraj,
+                           (const int*)active, Hs, (long)batch, T, (const int*)list, (long)count);
+    else
+        hipLaunchKernelGGL((quad_hessian_pairs16_kernel<false, true>), grid16, block16, 0, (hipStream_t)stream, md, xTraj, uTraj,
+                           (const int*)active, Hs, (long)batch, T, (const int*)list, (long)count);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+}  // namespace zm
 
 extern "C" int zm_quadratic_dynamics_f64(const zm_model_t* model, const double* xTraj, const double* uTraj,
                                          const int32_t* active, double* f_xx, double* f_ux, double* f_uu, int64_t batch,
