@@ -217,8 +217,8 @@ __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], 
         double vtd = 0.0;  // (V^T d)[c]: column reduction
 #pragma unroll
         for (int s = 0; s < KS; ++s) vtd = __builtin_fma(Vxx[s], d.dr[s], vtd);
-        vtd += __shfl_xor(vtd, 16);
-        vtd += __shfl_xor(vtd, 32);
+        vtd = sum_xor16(vtd);
+        vtd = sum_xor32(vtd);
         if (g == 0) sm[96 + c] = a.cA ? vtd : 0.0;
         ilqr_lds_sync();
 #pragma unroll
@@ -235,8 +235,8 @@ __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], 
 #pragma unroll
         for (int s = 0; s < KS; ++s) qp = __builtin_fma(d.F[s], vxr[s], qp);
     }
-    qp += __shfl_xor(qp, 16);
-    qp += __shfl_xor(qp, 32);
+    qp = sum_xor16(qp);     // over the four lane groups: gfx950 row / half-wave swaps instead of two ds_bpermute round trips
+    qp = sum_xor32(qp);
     const double qv = d.cv + qp;
     if constexpr (PREFETCH) ilqr_load_step<KS, MODE>(d, a);
 

@@ -36,4 +36,25 @@ __device__ __forceinline__ void wave_lds_sync() {
 #endif
 }
 
+// v + (the value of lane ^ 16) resp. lane ^ 32, by the gfx950 row / half-wave swaps (VALU; __shfl_xor across rows is a ds_bpermute
+// round trip through LDS on the dependency chain).  permlane16_swap(a, b): odd rows of a <-> even rows of b; with a = b = v the two
+// results hold the even-row resp. odd-row partner values of every row pair, whose sum is the butterfly sum in both rows (fp addition
+// commutes: the same bits as v + __shfl_xor(v, 16)).  permlane32_swap likewise for the two half waves.
+__device__ __forceinline__ double sum_xor16(const double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+    const double x = __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | (unsigned long long)lo[0]);
+    const double y = __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | (unsigned long long)lo[1]);
+    return x + y;
+}
+__device__ __forceinline__ double sum_xor32(const double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+    const double x = __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | (unsigned long long)lo[0]);
+    const double y = __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | (unsigned long long)lo[1]);
+    return x + y;
+}
+
 }  // namespace zm
