@@ -268,15 +268,18 @@ __global__ __launch_bounds__(256) void ilqr_accept_kernel(const int* __restrict_
     // the new trajectory: row t of (xT2, uT2), or -- after an all-store line search (n = 12, m = 4) -- the winner's 16-byte pieces
     // of this slot's scratch blocks (layout: rollout_fast.hip, allstore)
     if (scratch) {
+        // 16-byte pieces: (T + 1) * 6 of x, T * 2 of u
         constexpr int n = 12, m = 4, PB = (n + m) / 2;
+        typedef double d2 __attribute__((ext_vector_type(2)));
         const double* sb = scratch + slot * (xrow / n) * (PB * 32) + idx[t] * 2;
-        for (long e = threadIdx.x; e < xrow; e += blockDim.x) {
-            const long k = e / n, i = e % n;
-            xT[t * xrow + e] = sb[(k * PB + (i >> 1)) * 32 + (i & 1)];
+        const long nxp = xrow / 2, nup = urow / 2;
+        for (long e = threadIdx.x; e < nxp; e += blockDim.x) {
+            const long k = e / (n / 2), p = e % (n / 2);
+            *(d2*)(xT + t * xrow + 2 * e) = *(const d2*)(sb + (k * PB + p) * 32);
         }
-        for (long e = threadIdx.x; e < urow; e += blockDim.x) {
-            const long k = e / m, i = e % m;
-            uT[t * urow + e] = sb[((k + 1) * PB + n / 2 + (i >> 1)) * 32 + (i & 1)];
+        for (long e = threadIdx.x; e < nup; e += blockDim.x) {
+            const long k = e / (m / 2), p = e % (m / 2);
+            *(d2*)(uT + t * urow + 2 * e) = *(const d2*)(sb + ((k + 1) * PB + n / 2 + p) * 32);
         }
     } else {
         for (long e = threadIdx.x; e < xrow; e += blockDim.x) xT[t * xrow + e] = xT2[t * xrow + e];
