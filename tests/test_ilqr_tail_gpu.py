@@ -23,7 +23,8 @@ x0 = np.zeros((B, 12)); x0[:, 9:12] = rng.uniform(-10, 10, (B, 3))
 ug = np.tile(models.QuadcopterEuler.uTrim, (B, N, 1))
 cost = models.QuadraticCost(np.eye(12), (0.2 if ddp else 1.0) * np.eye(4), 10 * np.eye(12))
 solve = ilqrUtils.differentialDynamicProgramming if ddp else ilqrUtils.iterativeLqr
-traj, L, J, conv = solve(models.QuadcopterEuler(0.1), cost, cost, x0, ug)
+wind = (3.0, 1.0, -0.5) if (len(sys.argv) > 4 and sys.argv[4] == "wind") else (0.0, 0.0, 0.0)
+traj, L, J, conv = solve(models.QuadcopterEuler(0.1, wind_ned=wind), cost, cost, x0, ug)
 np.savez(sys.argv[1], x=np.asarray(traj.xTraj), u=np.asarray(traj.uTraj), L=np.asarray(L), J=np.asarray(J), c=np.asarray(conv))
 print("CHILD-OK", int(np.sum(conv)))
 """ % ROOT
@@ -70,3 +71,32 @@ def test_short_and_odd_horizons_agree_across_line_search_forms(N, tmp_path):
     for case in cases[1:]:
         for k in ("x", "u", "L", "J", "c"):
             assert np.array_equal(res[cases[0]][k], res[case][k], equal_nan=True), (N, case, k)
+
+
+@pytest.mark.parametrize("solver", ["ilqr", "ddp"])
+def test_windy_model_packed_and_full_operands_agree_and_match_the_oracle(solver, tmp_path):
+    """A constant NED wind selects the wind forms of the generated derivatives (59 packed Jacobian entries, 85 sparse second derivatives)
+    and the generic rollout kernel: the solve with packed / sparse operands equals the solve with the full matrices and dense rows bit
+    for bit, and the iLQR result matches the oracle loop on the windy model."""
+    import importlib
+    res = {}
+    for jac, hes in (("packed", "sparse"), ("full", "dense")):
+        out = tmp_path / f"w_{solver}_{jac}.npz"
+        p = subprocess.run([sys.executable, "-c", CHILD, str(out), solver, "12", "wind"],
+                           env=dict(os.environ, ZOPT_AMD_JAC=jac, ZOPT_AMD_HES=hes), capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert p.returncode == 0 and "CHILD-OK" in p.stdout, (p.stdout[-300:], p.stderr[-1500:])
+        res[jac] = dict(np.load(out))
+    for k in ("x", "u", "L", "J", "c"):
+        assert np.array_equal(res["packed"][k], res["full"][k], equal_nan=True), (solver, k)
+    if solver == "ilqr":
+        sys.path.insert(0, ROOT)
+        zo = importlib.import_module("oracle.zopt_oracle")
+        wind = np.array([3.0, 1.0, -0.5])
+        step = lambda x, u: x + 0.1 * zo.quad_inertialDynamics(x, u, wind_ned=wind)
+        rng = np.random.default_rng(11)
+        x0 = np.zeros((96, 12)); x0[:, 9:12] = rng.uniform(-10, 10, (96, 3))
+        ug = np.tile(np.array([9.807, 0.0, 0.0, 0.0]), (12, 1))
+        for i in (0, 5):
+            rt, rL, rJ, rc = zo.iterativeLqr(step, np.eye(12), np.eye(4), 10 * np.eye(12), x0[i], ug)
+            assert bool(res["packed"]["c"][i]) == rc and abs(res["packed"]["J"][i] - rJ) <= 1e-7 * abs(rJ)
+            assert np.max(np.abs(res["packed"]["u"][i] - rt.uTraj)) <= 1e-6 * max(1.0, np.abs(rt.uTraj).max())
