@@ -8,7 +8,7 @@ full 16 x 16 tile needs (4 per product).  CPU only."""
 import numpy as np
 
 QA, QB, QC = 3.4445, -4.7750, 2.0315
-MAX_PAIRS, MAX_CUBIC = 18, 12
+MAX_PAIRS, MAX_CUBIC = 18, 14
 
 
 def eigh_projection(a, eps=1e-3):
@@ -41,10 +41,18 @@ def ns_projection(A, k, eps=1e-3, stats=None):
             mfma += 16
             pairs += 1
         else:
+            # cubic steps in twos (one reduction / one symmetrisation per two steps); F' = 0.5625 F^2 after a step
+            if F < 1e-16 or cubic + 1 >= MAX_CUBIC:
+                Z = sym(Z.T @ (1.5 * I - 0.5 * Z2))
+                mfma += 4
+                cubic += 1
+                break
+            Z = Z.T @ (1.5 * I - 0.5 * Z2)
+            Z2 = Z.T @ Z
             Z = sym(Z.T @ (1.5 * I - 0.5 * Z2))
-            mfma += 4
-            cubic += 1
-            if F < 1e-16 or cubic >= MAX_CUBIC:
+            mfma += 12
+            cubic += 2
+            if 0.5625 * F * F < 1e-18 or cubic >= MAX_CUBIC:
                 break
     if stats is not None:
         stats.append((pairs, cubic, mfma + 4))

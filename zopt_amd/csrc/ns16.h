@@ -86,7 +86,7 @@ __device__ __forceinline__ d4 ns_sign_times(d4 z, d4& x, const d4& idr, double* 
         ns_sync();
     }
     constexpr double QA = 3.4445, QB = -4.7750, QC = 2.0315;
-    constexpr int MAX_PAIRS = 18, MAX_CUBIC = 12;
+    constexpr int MAX_PAIRS = 18, MAX_CUBIC = 14;
     int pairs = 0, cubic = 0;
     for (;;) {
         d4 z2 = ns_op<K>(z, z);
@@ -111,11 +111,24 @@ __device__ __forceinline__ d4 ns_sign_times(d4 z, d4& x, const d4& idr, double* 
             z = ns_symmetrise(ns_op<K>(w, z), T, flip, g, c);
             ++pairs;
         } else {
+            // Cubic steps go in twos: the norm reduction and the symmetrising LDS transpose are paid once per two steps (an
+            // unsymmetrised intermediate amplifies its rounding asymmetry 3x -- harmless once; tools/ns_psd_model.py: same accuracy).
+            // F' = 0.5625 F^2 after a step, so the second step of a double is the final one when 0.5625 F^2 is far below 1e-16.
+            const bool last = (f < 1e-16) || (cubic + 1 >= MAX_CUBIC);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = 1.5 * idr[r] - 0.5 * z2[r];
+            if (last) {
+                z = ns_symmetrise(ns_op<K>(z, w), T, flip, g, c);
+                ++cubic;
+                break;
+            }
+            z = ns_op<K>(z, w);
+            z2 = ns_op<K>(z, z);
 #pragma unroll
             for (int r = 0; r < 4; ++r) w[r] = 1.5 * idr[r] - 0.5 * z2[r];
             z = ns_symmetrise(ns_op<K>(z, w), T, flip, g, c);
-            ++cubic;
-            if (f < 1e-16 || cubic >= MAX_CUBIC) break;
+            cubic += 2;
+            if (0.5625 * f * f < 1e-18 || cubic >= MAX_CUBIC) break;
         }
     }
     if (xstash) {
