@@ -135,7 +135,7 @@ __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], 
         pz = zin;                                    // projected by the caller
     } else if constexpr (MODE == 2 && ZIN == 1) {
         d4 zt = zin;
-        psd_project_ns<KS + 1>(zt, a.zlive, 1e-3, jA, g, c);
+        psd_project_ns<KS + 1, true>(zt, a.zlive, 1e-3, jA, g, c);   // (the ring kernel's contraction is bitwise symmetric)
         pz = zt;
     } else if constexpr (MODE == 2) {
         const int lane = g * 16 + c;

@@ -143,12 +143,14 @@ __device__ __forceinline__ d4 ns_sign_times(d4 z, d4& x, const d4& idr, double* 
 // KSZ: row groups that can hold live indices; the products run over the row groups that actually do (wave-uniform).
 // xstash: optional 256 doubles of wave-private LDS: X = a - eps I waits there during the iteration instead of in 8 registers (the
 // sweep kernel that wants a third wave per SIMD passes it)
-template <int KSZ>
+// SYMIN: the caller guarantees a bitwise symmetric tile (the DDP ring sweep contracts element (i, j) and (j, i) from the same packed row
+// in the same order): the input symmetrisation -- an identity then -- and its LDS round trip are skipped.
+template <int KSZ, bool SYMIN = false>
 __device__ __forceinline__ void psd_project_ns(d4& a, const bool (&live)[4], const double eps, double* T, const int g,
                                                const int c, double* xstash = nullptr) {
     int flip = 0;
     d4 x;
-    a = ns_symmetrise(a, T, flip, g, c);        // jnp.linalg.eigh symmetrises its input
+    if constexpr (!SYMIN) a = ns_symmetrise(a, T, flip, g, c);        // jnp.linalg.eigh symmetrises its input
     // An index whose row and column are exactly zero is an eigenvector with eigenvalue 0, decoupled from the rest: its projection
     // is eps on the diagonal, and it stays out of the iteration (idr).  Otherwise X would carry the eigenvalue -eps once per such
     // index -- 1e-4..1e-5 of |X| for the Hessians of a model that is affine in some of its variables -- and the sign iteration
