@@ -221,24 +221,37 @@ extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* c
     const int nh = windy ? zm::QUAD_NH_WIND : zm::QUAD_NH_STILL, nhs = (nh + 1) & ~1;
     const unsigned short* hdense = windy ? zm::QUAD_HDENSE_WIND : zm::QUAD_HDENSE_STILL;
     int32_t* widx = (int32_t*)(ws + w.idx);
+    // pinned word + event for the active count (kept for the life of the process: one per host thread)
+    static thread_local int32_t* hcount_pinned = nullptr;
+    static thread_local hipEvent_t count_ready = nullptr;
+    if (!hcount_pinned) {
+        ZM_HIP_CHECK(hipHostMalloc((void**)&hcount_pinned, sizeof(int32_t), hipHostMallocDefault));
+        ZM_HIP_CHECK(hipEventCreateWithFlags(&count_ready, hipEventDisableTiming));
+    }
     int it = 0;
     int64_t count = batch;
     for (; it < max_iter; ++it) {                                                                        // (:301-303)
-        // rebuild the id list on the device, learn how many trajectories are left.  (Measured: a longer interval once the active set
-        // is small does not pay -- the host round trip is hidden behind the launches already queued, a stale list costs the DDP tail 1-3 %.)
-        if (it % sync_every == 0) {
+        // Every `sync_every` iterations: rebuild the id list on the device and learn how many trajectories are left.  The expansion
+        // launch does not wait for that answer: it goes out behind the compaction with the PREVIOUS count (list entries past the new
+        // count are ids of the previous list: inactive ones are skipped by the mask, a still-active one is merely expanded twice --
+        // the same values into the same rows), and the host round trip (~45 us) passes while it runs.
+        // (Measured: a longer interval once the active set is small does not pay -- a stale list costs the DDP tail 1-3 %.)
+        const bool sync_now = (it % sync_every == 0);
+        if (sync_now) {
             hipLaunchKernelGGL(zm::compact_active_kernel, dim3(1), dim3(1024), 0, st, (const int*)active, (long)batch, (int*)list,
                                (int*)dcount);
-            int32_t hcount = 0;
-            ZM_HIP_CHECK(hipMemcpyAsync(&hcount, dcount, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            ZM_HIP_CHECK(hipStreamSynchronize(st));
-            count = hcount;
-            if (count == 0) break;
+            ZM_HIP_CHECK(hipMemcpyAsync(hcount_pinned, dcount, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            ZM_HIP_CHECK(hipEventRecord(count_ready, st));
         }
         // expansions along the current trajectories: [f_x | f_u], c_x, c_u, v_x in one launch                  (:304-313)
         rc = zm::expand_list(model, cost, xTraj, uTraj, list, count, active, ws + w.f_x, ws + w.f_u, ws + w.c_x, ws + w.c_u,
                              ws + w.v_x, batch, T, st, packed ? 1 : 0);
         if (rc) return rc;
+        if (sync_now) {
+            ZM_HIP_CHECK(hipEventSynchronize(count_ready));
+            count = *hcount_pinned;
+            if (count == 0) break;
+        }
         if (packed) {
             if (sparse_h) {
                 rc = zm::quad_hessian_sparse_list(model, xTraj, uTraj, list, count, active, ws + w.f_xx, batch, T, st);
