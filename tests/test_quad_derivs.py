@@ -147,6 +147,14 @@ def test_sparse_second_derivative_image_rebuilds_the_dense_rows(shim, wind):
         assert np.array_equal(R.reshape(len(PAIRS), 12), dt * H)          # same expressions, same bits; and nothing nonzero is left out
 
 
+def test_regenerating_the_header_reproduces_the_file_in_the_tree(tmp_path):
+    """tools/gen_quad_derivs.py --out <tmp>: byte for byte zopt_amd/csrc/quad_derivs_gen.h (nobody edited one without the other)"""
+    out = tmp_path / "quad_derivs_gen.h"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_quad_derivs.py"), "--out", str(out)], check=True, timeout=600,
+                   capture_output=True)
+    assert open(out).read() == open(os.path.join(ROOT, "zopt_amd", "csrc", "quad_derivs_gen.h")).read()
+
+
 def test_header_is_what_the_generator_writes(tmp_path):
     import importlib.util
     spec = importlib.util.spec_from_file_location("gen_quad_derivs", os.path.join(ROOT, "tools", "gen_quad_derivs.py"))

@@ -155,7 +155,7 @@ def derivatives(wind):
 
 def main():
     pr = Printer()
-    out = os.path.join(ROOT, "zopt_amd", "csrc", "quad_derivs_gen.h")
+    out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(ROOT, "zopt_amd", "csrc", "quad_derivs_gen.h")
     d = {wind: derivatives(wind) for wind in (False, True)}
     nnz1 = sum(len(v) for v in d[True][0].values())
     nnz2 = sum(len(v) for v in d[True][1].values())
