@@ -221,13 +221,20 @@ extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* c
     const int nh = windy ? zm::QUAD_NH_WIND : zm::QUAD_NH_STILL, nhs = (nh + 1) & ~1;
     const unsigned short* hdense = windy ? zm::QUAD_HDENSE_WIND : zm::QUAD_HDENSE_STILL;
     int32_t* widx = (int32_t*)(ws + w.idx);
-    // pinned word + event for the active count (kept for the life of the process: one per host thread)
-    static thread_local int32_t* hcount_pinned = nullptr;
-    static thread_local hipEvent_t count_ready = nullptr;
-    if (!hcount_pinned) {
-        ZM_HIP_CHECK(hipHostMalloc((void**)&hcount_pinned, sizeof(int32_t), hipHostMallocDefault));
-        ZM_HIP_CHECK(hipEventCreateWithFlags(&count_ready, hipEventDisableTiming));
+    // pinned word + event for the active count: one pair per (host thread, device), created on first use and kept (a pinned allocation
+    // per solve costs ~1 ms; an event belongs to the device that was current when it was created)
+    constexpr int MAXDEV = 64;
+    static thread_local int32_t* words[MAXDEV] = {nullptr};
+    static thread_local hipEvent_t events[MAXDEV] = {nullptr};
+    int dev = 0;
+    ZM_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAXDEV) return zm::set_error(ZM_EUNSUPPORTED, "zm_ilqr_solve_f64: device index %d", dev);
+    if (!words[dev]) {
+        ZM_HIP_CHECK(hipHostMalloc((void**)&words[dev], sizeof(int32_t), hipHostMallocDefault));
+        ZM_HIP_CHECK(hipEventCreateWithFlags(&events[dev], hipEventDisableTiming));
     }
+    int32_t* const hcount_pinned = words[dev];
+    const hipEvent_t count_ready = events[dev];
     int it = 0;
     int64_t count = batch;
     for (; it < max_iter; ++it) {                                                                        // (:301-303)
