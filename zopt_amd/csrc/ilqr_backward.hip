@@ -560,8 +560,11 @@ struct IlqrDmaGeom {
 #ifndef ZM_ILQR_DMA_WAVES
 #define ZM_ILQR_DMA_WAVES 3
 #endif
-template <int N, int M, int D, bool SHARED, int MODE, int NPAIR = 0, int NJP = 0, int NHS = 0>
-__global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVES) void ilqr_backward_dma_f64(
+// W: waves per workgroup, wave w of block b works on slot b * W + w (list form only).  The waves share nothing; what W = 4 buys is
+// PLACEMENT when few trajectories are left: the four waves of a workgroup go to the four SIMDs of a CU, whereas single-wave workgroups
+// start doubling up on SIMDs beyond three per CU (768 waves: measured 148 against 119 us per sweep at 808 resp. 758 trajectories).
+template <int N, int M, int D, bool SHARED, int MODE, int NPAIR = 0, int NJP = 0, int NHS = 0, int W = 1>
+__global__ __launch_bounds__(64 * W, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVES) void ilqr_backward_dma_f64(
     const double* __restrict__ f_x, const double* __restrict__ f_u, const double* __restrict__ c_x,
     const double* __restrict__ c_u, const double* __restrict__ c_xx, const double* __restrict__ c_ux,
     const double* __restrict__ c_uu, const double* __restrict__ vf_x, const double* __restrict__ vf_xx,
@@ -581,15 +584,21 @@ __global__ __launch_bounds__(64, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_WAVE
 #define ZM_DDP_LDS_PAD 0
 #endif
     constexpr int HDN = NHS ? NPAIR * N : 0;   // dense image of the sparse second derivatives
-    __shared__ __attribute__((aligned(16))) char lds[SMO + ILQR_LDS_DOUBLES * 8 + (MODE == 2 ? NS_LDS_DOUBLES * 8 + ZM_DDP_LDS_PAD : 0) + (XST + VST + CST + HDN) * 8];
+    constexpr int PER_WAVE = SMO + ILQR_LDS_DOUBLES * 8 + (MODE == 2 ? NS_LDS_DOUBLES * 8 + ZM_DDP_LDS_PAD : 0) + (XST + VST + CST + HDN) * 8;
+    static_assert(PER_WAVE % 16 == 0, "per-wave LDS slices stay 16-B aligned");
+    __shared__ __attribute__((aligned(16))) char lds_all[W * PER_WAVE];
+    const int wave = (W == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    char* const lds = lds_all + wave * PER_WAVE;
     double* sm = (double*)(lds + SMO);
     double* jA = (double*)(lds + SMO + ILQR_LDS_DOUBLES * 8);   // MODE 2: transpose buffers of the sign iteration (ns16.h)
     double* xst = jA + NS_LDS_DOUBLES;
     double* vst = xst + XST;
     double* cst = vst + VST;
     double* hd = cst + CST;
-    const int lane = threadIdx.x;
-    const long traj = tl.list ? (long)tl.list[blockIdx.x] : (long)blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const long slot_ = (long)blockIdx.x * W + wave;
+    if (W > 1 && slot_ >= tl.count) return;    // (W > 1: list form; whole waves only, no barrier anywhere in this kernel)
+    const long traj = tl.list ? (long)tl.list[slot_] : slot_;
     if (active && active[traj] == 0) return;   // whole wave leaves: this trajectory keeps its previous policy
     const int g = lane >> 4, c = lane & 15;
     const bool cA = c < N, cB = (c >= N) && (c < N + M);
@@ -902,10 +911,25 @@ int sweep_packed_jacobians(const double* Fp, int njp, const unsigned char* pos, 
     HTab ht{};
     for (int e = 0; e < nh && nhs; ++e) ht.dense[e] = hdense[e];
     ht.n = nhs ? nh : 0;
-    const dim3 grid((unsigned)(tl.list ? tl.count : batch)), block(64);
+    const long nslot = tl.list ? tl.count : batch;
+    // few trajectories left (at most one wave per SIMD): four-wave workgroups, one wave per SIMD of a CU
+    static const long wg4_max = [] {   // ZOPT_AMD_SWEEP_WG4=<n>: four-wave workgroups up to n listed trajectories (A/B)
+        const char* e = getenv("ZOPT_AMD_SWEEP_WG4");
+        return e ? atol(e) : 1024L;
+    }();
+    const bool quad_wg = tl.list && nslot <= wg4_max;
+    const dim3 grid((unsigned)(quad_wg ? (nslot + 3) / 4 : nslot)), block(quad_wg ? 256 : 64);
 #define ZM_LAUNCH_PACKED(DD, MODE_, NPAIR_, NJP_, NHS_)                                                                               \
-    hipLaunchKernelGGL((ilqr_backward_dma_f64<12, 4, DD, true, MODE_, NPAIR_, NJP_, NHS_>), grid, block, 0, st, Fp, (const double*)nullptr,  \
-                       c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, (const double*)nullptr, 12L, 0L, act, l, L, T, tl, Hpk, ptab, jt, ht)
+    do {                                                                                                                              \
+        if (quad_wg)                                                                                                                  \
+            hipLaunchKernelGGL((ilqr_backward_dma_f64<12, 4, DD, true, MODE_, NPAIR_, NJP_, NHS_, 4>), grid, block, 0, st, Fp,         \
+                               (const double*)nullptr, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, (const double*)nullptr, 12L, 0L, act, l, \
+                               L, T, tl, Hpk, ptab, jt, ht);                                                                          \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((ilqr_backward_dma_f64<12, 4, DD, true, MODE_, NPAIR_, NJP_, NHS_>), grid, block, 0, st, Fp,            \
+                               (const double*)nullptr, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, (const double*)nullptr, 12L, 0L, act, l, \
+                               L, T, tl, Hpk, ptab, jt, ht);                                                                          \
+    } while (0)
     if (Hpk && nhs) {
         if (njp == 56) ZM_LAUNCH_PACKED(2, 2, 28, 56, 70); else ZM_LAUNCH_PACKED(2, 2, 28, 60, 86);
     } else if (Hpk) {
