@@ -34,6 +34,11 @@ def ns_projection(A, k, eps=1e-3, stats=None):
         mfma += 4
         F = np.sum((I - Z2) ** 2)
         if F > 0.9 and pairs < MAX_PAIRS:
+            if F > 1.9:      # at least two eigenvalues far below the band: a second quintic rides along (one reduction per 8 products)
+                Z4 = Z2.T @ Z2
+                Z = (QA * I + QB * Z2 + QC * Z4).T @ Z
+                Z2 = Z.T @ Z
+                mfma += 12
             Z4 = Z2.T @ Z2
             Z = (QA * I + QB * Z2 + QC * Z4).T @ Z        # W bitwise symmetric: W^T Z = W Z; symmetrised after the cubic step
             Z2 = Z.T @ Z

@@ -99,6 +99,17 @@ __device__ __forceinline__ d4 ns_sign_times(d4 z, d4& x, const d4& idr, double* 
         f = ns_wave_sum(f);
         d4 w;
         if (f > 0.9 && pairs < MAX_PAIRS) {
+            if (f > 1.9) {
+                // at least two eigenvalues are still far below the band: a second quintic rides along before the pair's own (gain
+                // 3.44^2 * 1.5 = 17.8 for 8 products and ONE reduction / transpose, instead of 5.17^2 = 26.7 for 10 products and two);
+                // its result stays unsymmetrised like the pair's quintic (tools/ns_psd_model.py: same accuracy, 5 % fewer products and
+                // two reductions fewer per matrix on the DDP sweeps' spectra)
+                const d4 y4 = ns_op<K>(z2, z2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[r] = __builtin_fma(QC, y4[r], __builtin_fma(QB, z2[r], QA * idr[r]));
+                z = ns_op<K>(w, z);
+                z2 = ns_op<K>(z, z);
+            }
             const d4 z4 = ns_op<K>(z2, z2);
 #pragma unroll
             for (int r = 0; r < 4; ++r) w[r] = __builtin_fma(QC, z4[r], __builtin_fma(QB, z2[r], QA * idr[r]));
