@@ -34,7 +34,7 @@ def ns_projection(A, k, eps=1e-3, stats=None):
         mfma += 4
         F = np.sum((I - Z2) ** 2)
         if F > 0.9 and pairs < MAX_PAIRS:
-            if F > 1.9:      # at least two eigenvalues far below the band: a second quintic rides along (one reduction per 8 products)
+            if F > 0.9:      # (always, in a booster group) a second quintic rides along: one reduction and transpose per 8 products
                 Z4 = Z2.T @ Z2
                 Z = (QA * I + QB * Z2 + QC * Z4).T @ Z
                 Z2 = Z.T @ Z

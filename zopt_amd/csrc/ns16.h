@@ -6,9 +6,11 @@
 // and sign(X) comes from matrix iterations that are nothing but 16x16 products -- the work fp64 MFMA is built for:
 //   cubic   Newton-Schulz step  Z <- Z (3 I - Z^2) / 2                           (quadratically convergent near |x| = 1)
 //   quintic booster        step  Z <- Z (a I + b Z^2 + c Z^4), a = 3.4445        (x -> 3.44 x for small x, [0.7, 1.2] invariant)
-// A (quintic, cubic) pair runs while F = |I - Z^2|_F^2 > 0.9, i.e. while some eigenvalue may still be below 0.23 (after a pair
-// every eigenvalue that has reached the band contributes < 0.052 to F, 16 of them < 0.9); plain cubic steps finish.  An eigenvalue
-// of X below ~1e-12 |X|_F is not resolved within the iteration caps; it then contributes an error of at most its own size.
+// A (quintic, quintic, cubic) group runs while F = |I - Z^2|_F^2 > 0.9, i.e. while some eigenvalue may still be below 0.23 (after a
+// group every eigenvalue that has reached the band contributes < 0.052 to F, 16 of them < 0.9); cubic steps, two per convergence test,
+// finish.  One reduction (F) and one LDS transpose (the symmetrisation) per group / per two cubic steps: they cost a wave about as much
+// as two of the products, which is why the steps come in groups.  An eigenvalue of X below ~1e-12 |X|_F is not resolved
+// within the iteration caps; it then contributes an error of at most its own size.
 // Measured against eigh on 900 adversarial spectra (tools/ns_psd_model.py): <= 4e-12 relative, 3e-15 on dense random matrices.
 //
 // The tile algebra gives X^T Y for free (tile16_f64.h); Z is symmetric, so X^T Y = X Y -- but rounding makes Z' = Z^T W slightly
@@ -76,6 +78,14 @@ __device__ __forceinline__ d4 ns_symmetrise(const d4& v, double* T, int& flip, c
     return o;
 }
 
+// thresholds on F = ||I - Z^2||_F^2 above which one / two further quintics ride along in a booster pair (see below)
+#ifndef NS_RIDER1
+#define NS_RIDER1 0.9
+#endif
+#ifndef NS_RIDER2
+#define NS_RIDER2 1e300
+#endif
+
 // sign iteration on Z (scaled X) over K row groups; returns |X| = sign(X) X
 template <int K>
 __device__ __forceinline__ d4 ns_sign_times(d4 z, d4& x, const d4& idr, double* T, int& flip, const int g, const int c,
@@ -99,11 +109,11 @@ __device__ __forceinline__ d4 ns_sign_times(d4 z, d4& x, const d4& idr, double* 
         f = ns_wave_sum(f);
         d4 w;
         if (f > 0.9 && pairs < MAX_PAIRS) {
-            if (f > 1.9) {
-                // at least two eigenvalues are still far below the band: a second quintic rides along before the pair's own (gain
-                // 3.44^2 * 1.5 = 17.8 for 8 products and ONE reduction / transpose, instead of 5.17^2 = 26.7 for 10 products and two);
-                // its result stays unsymmetrised like the pair's quintic (tools/ns_psd_model.py: same accuracy, 5 % fewer products and
-                // two reductions fewer per matrix on the DDP sweeps' spectra)
+            // while eigenvalues are still far below the band further quintics ride along before the pair's own (each: gain 3.44 for
+            // 3 products and NO reduction / transpose; a pair alone is gain 5.17 for 5 products and one of each); their results stay
+            // unsymmetrised like the pair's quintic (tools/ns_psd_model.py: accuracy and counts on the DDP sweeps' spectra)
+            const int riders = (f > NS_RIDER1 ? 1 : 0) + (f > NS_RIDER2 ? 1 : 0);
+            for (int e = 0; e < riders; ++e) {
                 const d4 y4 = ns_op<K>(z2, z2);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) w[r] = __builtin_fma(QC, y4[r], __builtin_fma(QB, z2[r], QA * idr[r]));
