@@ -22,4 +22,4 @@ run tiled     $R/tools/bench_lqr_tiled.py --batch 2048 --reps 2
 run sweeps    $R/tools/bench_ilqr_backward.py --reps 3
 run ddp       $R/tools/bench_ilqr.py --ddp --reps 1
 run psd       $R/tools/bench_psd.py
-grep -h "metric\|workload\|kernel\|count" $OUT/*.log | cut -c1-400 > $OUT/results.jsonl
+grep -h "^{" $OUT/*.log | cut -c1-400 > $OUT/results.jsonl
