@@ -378,10 +378,15 @@ int rollout_fast_dispatch(const zm_model_t& md, const double* Q, const double* R
     }();
     const bool quad = quad_on && md.kind == ZM_MODEL_QUADCOPTER && diagonal == 1 && n_alpha == 16 && J && idx;
     const QuadArgs qa{md.dt, Q, R, Qf, x0, l, L, xPrev, uPrev, alphas, active, list, (long)count, xTraj, uTraj, J, idx, (long)batch, T, scratch};
-    // all-store line search with at most ~0.6 waves per SIMD: one trajectory per wave, 4 lanes per step size (78 against 104 us per
-    // launch).  With more trajectories its 4x as many waves no longer run alone and the 4-trajectories-per-wave kernel is faster
-    // (measured: 1131 trajectories 145 against ~125 us).
-    if (quad && scratch && count <= 640) return rollout_quad_all(qa, st);
+    // all-store line search with at most one wave per SIMD: one trajectory per wave, 4 lanes per step size (78 against 104 us per
+    // launch; four-wave workgroups so that up to 1024 waves each get a SIMD).  With more trajectories its 4x as many waves no longer
+    // run alone and the 4-trajectories-per-wave kernel is faster (measured: 1131 trajectories 145 against ~125 us; iLQR solve with the
+    // switch-over at 640 / 800 / 1024 / 1280 trajectories: 42.65 / 42.4 / 42.3 / 43.0 ms).
+    static const long quad_all_max = [] {   // ZOPT_AMD_QUAD_ALL_MAX: A/B of the switch-over (same results either side)
+        const char* e = getenv("ZOPT_AMD_QUAD_ALL_MAX");
+        return e ? atol(e) : 1024L;
+    }();
+    if (quad && scratch && count <= quad_all_max) return rollout_quad_all(qa, st);
     if (quad && !scratch) g.no_pass2 = 1;                              // two-pass line search: the second pass as its own, densely packed launch
     int rc;
     if (md.kind == ZM_MODEL_QUADCOPTER) rc = launch_fast<ZM_MODEL_QUADCOPTER>(g, diagonal == 1, st);

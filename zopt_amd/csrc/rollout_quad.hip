@@ -93,9 +93,12 @@ __device__ __forceinline__ void quad_step(const QuadOps& o, const int q, const d
     for (int i = 0; i < QN; ++i) x[i] = xn[i];
 }
 
-__global__ __launch_bounds__(64) void rollout_quad_all_kernel(const QuadArgs g) {
-    const int lane = threadIdx.x, q = lane & 3, a = lane >> 2;
-    const long slot = blockIdx.x;
+// Four-wave workgroups, one trajectory per wave and no barrier: a workgroup's waves go to the four SIMDs of a CU, whereas single-wave
+// workgroups beyond three per CU start sharing a SIMD while another is free.
+__global__ __launch_bounds__(256) void rollout_quad_all_kernel(const QuadArgs g) {
+    const int lane = threadIdx.x & 63, q = lane & 3, a = lane >> 2;
+    const long slot = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= g.count) return;
     const long t = g.list ? (long)g.list[slot] : slot;
     if (g.active && g.active[t] == 0) return;   // whole wave: one trajectory
     const int T = g.T;
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(64) void rollout_quad_reroll_kernel(const QuadArgs 
 
 // rollout_fast.hip decides when these apply (quadcopter in still air, diagonal weights asserted, 16 step sizes)
 int rollout_quad_all(const QuadArgs& g, hipStream_t st) {
-    hipLaunchKernelGGL(rollout_quad_all_kernel, dim3((unsigned)g.count), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(rollout_quad_all_kernel, dim3((unsigned)((g.count + 3) / 4)), dim3(256), 0, st, g);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }
