@@ -64,3 +64,16 @@ extern "C" int quad_hessian_sparse(const double* x, const double* u, const doubl
     for (int e = 0; e < nh; ++e) dense[e] = p[e];
     return nh;
 }
+
+// the straight-line forms (one lane per trajectory point on the device): the same images by quad_jac_all_packed / quad_hess_all_packed
+extern "C" void quad_all_packed(const double* x, const double* u, const double* w, int still_air, double dt, double* tj /* >= 60 */,
+                                double* th /* >= 86 */) {
+    const zm::QuadAtoms a = atoms(x, u, w);
+    if (still_air) {
+        zm::quad_jac_all_packed<false>(a, dt, tj);
+        zm::quad_hess_all_packed<false>(a, dt, th);
+    } else {
+        zm::quad_jac_all_packed<true>(a, dt, tj);
+        zm::quad_hess_all_packed<true>(a, dt, th);
+    }
+}

@@ -31,6 +31,8 @@ def shim(tmp_path_factory):
     lib.quad_jacobian_packed.restype = ctypes.c_int
     lib.quad_hessian_sparse.argtypes = [dp, dp, dp, ctypes.c_int, ctypes.c_double, dp, ctypes.POINTER(ctypes.c_ushort)]
     lib.quad_hessian_sparse.restype = ctypes.c_int
+    lib.quad_all_packed.argtypes = [dp, dp, dp, ctypes.c_int, ctypes.c_double, dp, dp]
+    lib.quad_all_packed.restype = None
     return lib
 
 
@@ -145,6 +147,27 @@ def test_sparse_second_derivative_image_rebuilds_the_dense_rows(shim, wind):
         R = np.zeros(len(PAIRS) * 12)
         R[dense[:nh]] = t[:nh]
         assert np.array_equal(R.reshape(len(PAIRS), 12), dt * H)          # same expressions, same bits; and nothing nonzero is left out
+
+
+@pytest.mark.parametrize("wind", [(0.0, 0.0, 0.0), (3.0, 1.0, -0.5)])
+@pytest.mark.parametrize("dt", [0.1, 0.0])
+def test_straight_line_forms_equal_the_per_column_and_per_pair_forms_bit_for_bit(shim, wind, dt):
+    """quad_jac_all_packed / quad_hess_all_packed (one lane evaluates a whole point: expand_quad_points_kernel,
+    quad_hessian_points_kernel) write the images of quad_jac_column_packed / quad_hess_pair2_packed: the generator spells every
+    multiply-add out and switches the compiler's contraction off, so the two forms round identically"""
+    w = np.array(wind)
+    still = 0 if np.any(w) else 1
+    for x, u in _points(7, 10):
+        t = np.full(64, np.nan)
+        pos = np.zeros(192, dtype=np.uint8)
+        nj = shim.quad_jacobian_packed(_p(x), _p(u), _p(w), still, dt, _p(t), pos.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)))
+        th = np.full(96, np.nan)
+        dense = np.zeros(96, dtype=np.uint16)
+        nh = shim.quad_hessian_sparse(_p(x), _p(u), _p(w), still, dt, _p(th), dense.ctypes.data_as(ctypes.POINTER(ctypes.c_ushort)))
+        aj, ah = np.full(64, np.nan), np.full(96, np.nan)
+        shim.quad_all_packed(_p(x), _p(u), _p(w), still, dt, _p(aj), _p(ah))
+        assert np.array_equal(aj[:nj], t[:nj]) and np.all(np.isnan(aj[nj:]))
+        assert np.array_equal(ah[:nh], th[:nh]) and np.all(np.isnan(ah[nh:]))
 
 
 def test_regenerating_the_header_reproduces_the_file_in_the_tree(tmp_path):

@@ -65,11 +65,52 @@ def to_atoms(e, x):
 class Printer(C99CodePrinter):
     def _print_Pow(self, e):
         if e.exp.is_Integer and 2 <= int(e.exp) <= 4:
-            b = self._print(e.base)
-            if not e.base.is_Atom:
-                b = "(" + b + ")"
+            b = self._factor(e.base)
             return "(" + " * ".join([b] * int(e.exp)) + ")"
         return super()._print_Pow(e)
+
+    # Sums and products are spelled out operation by operation -- products left to right in sympy's canonical factor order, sums as a
+    # chain of explicit fused multiply-adds -- and the generated functions switch the compiler's own contraction off (ZM_FP_STRICT):
+    # the per-column / per-pair forms (behind a switch) and the straight-line forms then run the SAME sequence of roundings, whatever
+    # code surrounds them, and agree bit for bit.
+    def _factor(self, f):
+        t = self._print(f)
+        return t if (f.is_Atom or t.startswith("(") or t.startswith("__builtin_fma(")) else "(" + t + ")"
+
+    def _product(self, factors):
+        return "(" + " * ".join(self._factor(f) for f in factors) + ")" if len(factors) > 1 else self._factor(factors[0])
+
+    def _print_Mul(self, e):
+        c, rest = e.as_coeff_Mul()
+        fs = list(rest.as_ordered_factors())
+        if any(f.is_Pow and f.exp.is_negative for f in fs):
+            raise ValueError(f"division left in {e}")
+        if c == 1:
+            return self._product(fs)
+        if c == -1:
+            return "(-" + self._product(fs) + ")"
+        return "(" + repr(float(c)) + " * " + self._product(fs) + ")"
+
+    def _print_Add(self, e):
+        terms = e.as_ordered_terms()
+        simple = [t for t in terms if not (t.is_Mul and len(t.as_coeff_Mul()[1].as_ordered_factors()) + (abs(t.as_coeff_Mul()[0]) != 1) >= 2)]
+        prods = [t for t in terms if t not in simple]
+        acc = None
+        for t in simple:
+            c, rest = t.as_coeff_Mul() if t.is_Mul else (sp.Integer(1), t)
+            if t.is_Mul and c == -1:
+                acc = ("(-" + self._factor(rest) + ")") if acc is None else "(" + acc + " - " + self._factor(rest) + ")"
+            else:
+                acc = self._factor(t) if acc is None else "(" + acc + " + " + self._factor(t) + ")"
+        for t in prods:
+            c, rest = t.as_coeff_Mul()
+            fs = list(rest.as_ordered_factors())
+            if abs(c) != 1:
+                a, b = repr(float(c)), self._product(fs)
+            else:
+                a, b = ("-" if c == -1 else "") + self._factor(fs[0]), self._product(fs[1:])
+            acc = "(" + a + " * " + b + ")" if acc is None else "__builtin_fma(" + a + ", " + b + ", " + acc + ")"
+        return acc
 
     def _print_Symbol(self, s):
         n = s.name
@@ -132,6 +173,22 @@ def emit_body(fh, table, pr, ind, packed=None, delta=True):
     return shared_ops, case_ops
 
 
+def emit_all(fh, table, pr, ind, packed, delta):
+    """Straight-line form of emit_body's packed output: the same CSE (same expression list, same order -> same temporaries), every
+    temporary and every entry evaluated by the calling lane -- one lane per trajectory point instead of one per column / pair."""
+    keys = [(c, i) for c in sorted(table) for i, _ in table[c]]
+    exprs = [e for c in sorted(table) for _, e in table[c]]
+    temps, outs = sp.cse(exprs, symbols=sp.numbered_symbols("t"), optimizations="basic")
+    for t, e in temps:
+        fh.write(f"{ind}const double {t} = {pr.doprint(e)};\n")
+    for (c, i), o in zip(keys, outs):
+        if delta:
+            fh.write(f"{ind}t[{packed[(i, c)]}] = (dt == 0.0) ? ({pr.doprint(o)}) : __builtin_fma(dt, {pr.doprint(o)}, {1.0 if i == c else 0.0});\n")
+        else:
+            fh.write(f"{ind}t[{packed[(i, c)]}] = (dt == 0.0) ? ({pr.doprint(o)}) : dt * ({pr.doprint(o)});\n")
+    return sum(sp.count_ops(e) for _, e in temps) + sum(sp.count_ops(o) for o in outs)
+
+
 def derivatives(wind):
     """-> (jac {column -> [(i, expr)]}, hes {pair -> [(i, expr)]}) in terms of the kernel's atoms; wind False: still air (w = 0)"""
     x, u, w, xd = model()
@@ -171,6 +228,8 @@ def main():
         fh.write("// Each case is a real branch on the device: without the (empty, volatile) asm the compiler may turn the switch into selects --\n"
                  "// every lane evaluating every case.\n"
                  "#if defined(__HIP_DEVICE_COMPILE__)\n#define ZM_CASE_FENCE __asm__ volatile(\"\");\n#else\n#define ZM_CASE_FENCE\n#endif\n\n")
+        fh.write("// The generated expressions spell their fused multiply-adds out; the compiler adds or removes none (see the generator's printer).\n"
+                 "#if defined(__clang__)\n#define ZM_FP_STRICT _Pragma(\"clang fp contract(off)\")\n#else\n#define ZM_FP_STRICT\n#endif\n\n")
         fh.write("namespace zm {\n\n")
         fh.write("// what the closed forms read: the state, the thrust, the NED wind, sin / cos of phi (6), theta (7), psi (8), 1 / cos(theta)\n")
         fh.write("struct QuadAtoms {\n    double x[12], u0, w[3], s6, c6, s7, c7, s8, c8, ic7;\n};\n\n")
@@ -184,7 +243,7 @@ def main():
                 ("quad_hess_pair2", lambda w: two_pairs(d[w][1]), 24,
                  "two declared pairs per case: o[i] = d2 xd_i for pair 2j, o[12 + i] for pair 2j+1 (14 cases: a 16-lane group per point)")):
             fh.write(f"// {doc}; entries not assigned are zero.  Temporaries shared by several cases are computed before the switch.\n")
-            fh.write(f"template <bool WIND>\nZM_HD void {fn}(const int j, const QuadAtoms& a, double (&o)[{nout}]) {{\n")
+            fh.write(f"template <bool WIND>\nZM_HD void {fn}(const int j, const QuadAtoms& a, double (&o)[{nout}]) {{\n    ZM_FP_STRICT\n")
             fh.write(f"    for (int i = 0; i < {nout}; ++i) o[i] = 0.0;\n    if constexpr (WIND) {{\n")
             stats[(fn, True)] = emit_body(fh, table(True), pr, "        ")
             fh.write("    } else {\n")
@@ -208,11 +267,19 @@ def main():
             fh.write("};\n\n")
             d[wind] = d[wind] + (pos,)
         fh.write("// column j of the PACKED image: t[pos] = dt * d xd_i / d z_j + (i == j) for the column's nonzero entries (dt = 0: the derivative itself)\n")
-        fh.write("template <bool WIND>\nZM_HD void quad_jac_column_packed(const int j, const QuadAtoms& a, const double dt, double* t) {\n")
+        fh.write("template <bool WIND>\nZM_HD void quad_jac_column_packed(const int j, const QuadAtoms& a, const double dt, double* t) {\n    ZM_FP_STRICT\n")
         fh.write("    if constexpr (WIND) {\n")
         emit_body(fh, d[True][0], pr, "        ", packed=d[True][2])
         fh.write("    } else {\n")
         emit_body(fh, d[False][0], pr, "        ", packed=d[False][2])
+        fh.write("    }\n}\n\n")
+        fh.write("// the whole PACKED image by one lane (one lane per trajectory point): t[0 .. QUAD_NJ) as quad_jac_column_packed writes them, same\n"
+                 "// temporaries and expressions\n")
+        fh.write("template <bool WIND>\nZM_HD void quad_jac_all_packed(const QuadAtoms& a, const double dt, double* t) {\n    ZM_FP_STRICT\n")
+        fh.write("    if constexpr (WIND) {\n")
+        stats[("quad_jac_all_packed", True)] = (emit_all(fh, d[True][0], pr, "        ", d[True][2], True), 0)
+        fh.write("    } else {\n")
+        stats[("quad_jac_all_packed", False)] = (emit_all(fh, d[False][0], pr, "        ", d[False][2], True), 0)
         fh.write("    }\n}\n\n")
         # sparse second derivatives: of the 28 x 12 entries H[pair][i] only NH are structurally nonzero; the expansion writes those, the
         # DDP sweep scatters them into its dense LDS image (whose other entries stay zero)
@@ -242,13 +309,22 @@ def main():
 
         fh.write("// the SPARSE image of the second derivatives: case j writes t[k] = dt * d2 xd_i (dt = 0: the derivative itself) for the nonzero\n"
                  "// entries of pairs 2j and 2j+1 at their packed positions k (QUAD_HDENSE_*)\n")
-        fh.write("template <bool WIND>\nZM_HD void quad_hess_pair2_packed(const int j, const QuadAtoms& a, const double dt, double* t) {\n")
+        fh.write("template <bool WIND>\nZM_HD void quad_hess_pair2_packed(const int j, const QuadAtoms& a, const double dt, double* t) {\n    ZM_FP_STRICT\n")
         fh.write("    if constexpr (WIND) {\n")
         tab, pk = two_pairs_packed(d[True][1], d[True][3])
         emit_body(fh, tab, pr, "        ", packed=pk, delta=False)
         fh.write("    } else {\n")
         tab, pk = two_pairs_packed(d[False][1], d[False][3])
         emit_body(fh, tab, pr, "        ", packed=pk, delta=False)
+        fh.write("    }\n}\n\n")
+        fh.write("// the whole SPARSE image by one lane: t[0 .. QUAD_NH) as quad_hess_pair2_packed writes them\n")
+        fh.write("template <bool WIND>\nZM_HD void quad_hess_all_packed(const QuadAtoms& a, const double dt, double* t) {\n    ZM_FP_STRICT\n")
+        fh.write("    if constexpr (WIND) {\n")
+        tab, pk = two_pairs_packed(d[True][1], d[True][3])
+        stats[("quad_hess_all_packed", True)] = (emit_all(fh, tab, pr, "        ", pk, False), 0)
+        fh.write("    } else {\n")
+        tab, pk = two_pairs_packed(d[False][1], d[False][3])
+        stats[("quad_hess_all_packed", False)] = (emit_all(fh, tab, pr, "        ", pk, False), 0)
         fh.write("    }\n}\n\n")
         fh.write("}  // namespace zm\n")
     for k, v in stats.items():

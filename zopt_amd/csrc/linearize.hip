@@ -523,6 +523,131 @@ extern "C" int zm_linearize_dynamics_list_f64(const zm_model_t* model, const dou
     return ZM_OK;
 }
 
+namespace zm {
+// The solvers' expansion for the quadcopter, ONE LANE PER TRAJECTORY POINT (packed Jacobians + cost gradients).  With 16 lanes per
+// point (linearize_dynamics_kernel) a wave serves four points and pays the trigonometric values, the shared temporaries and -- its
+// lanes diverging over the columns -- every column's code for them: ~425 fp64 instructions per four points, which bound that launch
+// (0.30 ms per 8192 x 100 points where its stores need 0.1).  Here a lane evaluates the whole straight-line form of its point
+// (quad_jac_all_packed: the same temporaries and expressions, 119 operations in still air) into its row of a wave-private LDS tile,
+// and the wave then copies the tile out as the contiguous block it is in memory (a chunk = up to 64 consecutive points of one
+// trajectory: NJP doubles per point for the Jacobians, 12 and 4 for the gradients).  Four waves per workgroup, no barrier.
+// copy-out of a wave's LDS tile: `tot` consecutive doubles of the output block, element e from row e / ROW, column COL0 + e % ROW of
+// the tile; eight independent LDS reads in flight per lane before their stores
+template <int ROW, int COL0, int LD>
+__device__ __forceinline__ void tile_copy_out(double* __restrict__ op, const double* tile, const int tot, const int lane) {
+    for (int e0 = lane; e0 < tot; e0 += 64 * 8) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = e0 + 64 * q;
+            const int p = e / ROW;
+            v[q] = (e < tot) ? tile[p * LD + COL0 + (e - p * ROW)] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = e0 + 64 * q;
+            if (e < tot) op[e] = v[q];
+        }
+    }
+}
+
+constexpr int QP_WAVES = 4;
+template <bool WIND>
+__global__ __launch_bounds__(64 * QP_WAVES) void expand_quad_points_kernel(const zm_model_t md, const double* __restrict__ xTraj,
+                                                                           const double* __restrict__ uTraj,
+                                                                           const int* __restrict__ active, double* __restrict__ f_x,
+                                                                           const int T, const int* __restrict__ list, const long nslot,
+                                                                           const ExpandCost ec, const int per, const int nchunk) {
+    constexpr int NJ = WIND ? QUAD_NJ_WIND : QUAD_NJ_STILL, NJP = (NJ + 1) & ~1;
+    constexpr int LD = NJP + 16 + 1;   // a point's row: packed Jacobians, c_x, c_u; odd, so that the lanes' rows start in different banks
+    extern __shared__ __attribute__((aligned(16))) double qp_lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double* tile = qp_lds + (long)wv * 64 * LD;
+    const long chunk = (long)blockIdx.x * QP_WAVES + wv;
+    if (chunk >= nslot * nchunk) return;
+    const long slot = chunk / nchunk;
+    const int ch = (int)(chunk - slot * nchunk);
+    const long traj = list ? (long)list[slot] : slot;
+    if (active && active[traj] == 0) return;   // (whole wave)
+    const int k0 = ch * per;
+    const int np = (T - k0 < per) ? T - k0 : per;
+    const zm_quadcost_t& cs = ec.cs;
+    if (lane < np) {
+        const int k = k0 + lane;
+        const double* xk = xTraj + (traj * (T + 1) + k) * 12;
+        const double* uk = uTraj + (traj * T + k) * 4;
+        double xv[12], uv[4];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) xv[i] = xk[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) uv[i] = uk[i];
+        double* t = tile + lane * LD;
+        // cost gradients: the expressions of quadratize_cost_kernel / linearize_dynamics_kernel, in their order
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            double g;
+            if (cs.diagonal == 1) {
+                g = (cs.Q[j * 12 + j] + cs.Q[j * 12 + j]) * xv[j];
+            } else {
+                g = 0.0;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) g = __builtin_fma(cs.Q[j * 12 + i] + cs.Q[i * 12 + j], xv[i], g);
+            }
+            t[NJP + j] = g;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double g;
+            if (cs.diagonal == 1) {
+                g = (cs.R[j * 4 + j] + cs.R[j * 4 + j]) * uv[j];
+            } else {
+                g = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) g = __builtin_fma(cs.R[j * 4 + i] + cs.R[i * 4 + j], uv[i], g);
+            }
+            t[NJP + 12 + j] = g;
+        }
+        const QuadAtoms a = quad_atoms(md, xv, uv);
+        if (NJP != NJ) t[NJP - 1] = 0.0;
+        quad_jac_all_packed<WIND>(a, md.dt, t);
+    }
+    if (k0 + np == T && lane < 12) {   // terminal gradient from x_T, one lane per component
+        const double* xT = xTraj + (traj * (T + 1) + T) * 12;
+        const int j = lane;
+        double gv;
+        if (cs.diagonal == 1) {
+            gv = (cs.Qf[j * 12 + j] + cs.Qf[j * 12 + j]) * xT[j];
+        } else {
+            gv = 0.0;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) gv = __builtin_fma(cs.Qf[j * 12 + i] + cs.Qf[i * 12 + j], xT[i], gv);
+        }
+        ec.v_x[traj * 12 + j] = gv;
+    }
+    wave_lds_sync();
+    const long p0 = traj * T + k0;
+    tile_copy_out<NJP, 0, LD>(f_x + p0 * NJP, tile, np * NJP, lane);
+    tile_copy_out<12, NJP, LD>(ec.c_x + p0 * 12, tile, np * 12, lane);
+    tile_copy_out<4, NJP + 12, LD>(ec.c_u + p0 * 4, tile, np * 4, lane);
+}
+
+template <bool WIND>
+static int launch_expand_quad_points(const zm_model_t& md, const double* xTraj, const double* uTraj, const int* active, double* f_x,
+                                     const int T, const int* list, const long nslot, const ExpandCost& ec, hipStream_t st) {
+    constexpr int NJ = WIND ? QUAD_NJ_WIND : QUAD_NJ_STILL, NJP = (NJ + 1) & ~1, LD = NJP + 16 + 1;
+    const size_t bytes = (size_t)QP_WAVES * 64 * LD * sizeof(double);
+    static_assert((size_t)QP_WAVES * 64 * (((QUAD_NJ_WIND + 1) & ~1) + 17) * sizeof(double) <= 160 * 1024, "LDS tile of four waves");
+    const int nchunk = (T + 63) / 64, per = (T + nchunk - 1) / nchunk;
+    const long chunks = nslot * nchunk;
+    // per launch (cheap): the attribute is per device, and several devices may be driven from one process
+    ZM_HIP_CHECK(hipFuncSetAttribute((const void*)expand_quad_points_kernel<WIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL((expand_quad_points_kernel<WIND>), dim3((unsigned)((chunks + QP_WAVES - 1) / QP_WAVES)), dim3(64 * QP_WAVES), bytes,
+                       st, md, xTraj, uTraj, active, f_x, T, list, nslot, ec, per, nchunk);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+}  // namespace zm
+
 // Solver-internal (ilqr_solve.hip): the per-iteration expansions of the listed trajectories in ONE launch -- [f_x | f_u] as
 // zm_linearize_dynamics_list_f64, c_x / c_u / v_x as zm_quadratize_cost_list_f64 (same expressions; tests/test_ilqr_solve_gpu.py).
 namespace zm {
@@ -545,6 +670,15 @@ int expand_list(const zm_model_t* model, const zm_quadcost_t* cost, const double
     const ExpandCost ec{*cost, c_x, c_u, v_x};
     const bool windy = md.wind_ned[0] != 0.0 || md.wind_ned[1] != 0.0 || md.wind_ned[2] != 0.0;
     if (packed && (!quad || md.dt == 0.0)) return set_error(ZM_EUNSUPPORTED, "expand_list: packed Jacobians need the quadcopter with dt != 0");
+    // ZOPT_AMD_EXPAND=group: the packed expansion with 16 lanes per point (A/B; same results)
+    static const bool by_points = [] {
+        const char* e = getenv("ZOPT_AMD_EXPAND");
+        return !(e && e[0] == 'g');
+    }();
+    if (packed && by_points) {
+        if (windy) return launch_expand_quad_points<true>(md, xTraj, uTraj, (const int*)active, f_x, T, (const int*)list, (long)count, ec, (hipStream_t)stream);
+        return launch_expand_quad_points<false>(md, xTraj, uTraj, (const int*)active, f_x, T, (const int*)list, (long)count, ec, (hipStream_t)stream);
+    }
     if (packed && windy)
         hipLaunchKernelGGL((linearize_dynamics_kernel<true, true, true, true>), grid, block, 0, (hipStream_t)stream, md, xTraj, uTraj,
                            (const int*)active, (double*)nullptr, f_x, f_u, (long)batch, T, (const int*)list, (long)count, ec);
@@ -678,6 +812,53 @@ extern "C" int zm_quadratic_dynamics_pairs_list_f64(const zm_model_t* model, con
 
 // Solver-internal (ilqr_solve.hip): the quadcopter's second derivatives in SPARSE form for the listed trajectories
 namespace zm {
+// The sparse second derivatives with ONE LANE PER TRAJECTORY POINT, as expand_quad_points_kernel does the Jacobians: the lane runs the
+// straight-line form quad_hess_all_packed (143 operations in still air, 377 with wind -- quad_hessian_pairs16_kernel pays the
+// trigonometric values, the shared part and all 14 cases for every four points) into its LDS row; the wave copies the chunk's
+// contiguous block out.  W waves per workgroup (the wind form's rows leave room for three).
+template <bool WIND, int W>
+__global__ __launch_bounds__(64 * W) void quad_hessian_points_kernel(const zm_model_t md, const double* __restrict__ xTraj,
+                                                                     const double* __restrict__ uTraj, const int* __restrict__ active,
+                                                                     double* __restrict__ Hs, const int T, const int* __restrict__ list,
+                                                                     const long nslot, const int per, const int nchunk) {
+    constexpr int NH = WIND ? QUAD_NH_WIND : QUAD_NH_STILL, NHP = (NH + 1) & ~1, LD = NHP + 1;
+    extern __shared__ __attribute__((aligned(16))) double qp_lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double* tile = qp_lds + (long)wv * 64 * LD;
+    const long chunk = (long)blockIdx.x * W + wv;
+    if (chunk >= nslot * nchunk) return;
+    const long slot = chunk / nchunk;
+    const int ch = (int)(chunk - slot * nchunk);
+    const long traj = list ? (long)list[slot] : slot;
+    if (active && active[traj] == 0) return;   // (whole wave)
+    const int k0 = ch * per;
+    const int np = (T - k0 < per) ? T - k0 : per;
+    if (lane < np) {
+        const int k = k0 + lane;
+        const QuadAtoms at = quad_atoms(md, xTraj + (traj * (T + 1) + k) * 12, uTraj + (traj * T + k) * 4);
+        double* t = tile + lane * LD;
+        if (NHP != NH) t[NHP - 1] = 0.0;
+        quad_hess_all_packed<WIND>(at, md.dt, t);
+    }
+    wave_lds_sync();
+    tile_copy_out<NHP, 0, LD>(Hs + (traj * T + k0) * NHP, tile, np * NHP, lane);
+}
+
+template <bool WIND>
+static int launch_quad_hessian_points(const zm_model_t& md, const double* xTraj, const double* uTraj, const int* active, double* Hs,
+                                      const int T, const int* list, const long nslot, hipStream_t st) {
+    constexpr int NH = WIND ? QUAD_NH_WIND : QUAD_NH_STILL, NHP = (NH + 1) & ~1, LD = NHP + 1;
+    constexpr int W = (4 * 64 * LD * 8 <= 160 * 1024) ? 4 : 3;
+    static_assert(W * 64 * LD * 8 <= 160 * 1024, "LDS tile of the workgroup");
+    const size_t bytes = (size_t)W * 64 * LD * sizeof(double);
+    const int nchunk = (T + 63) / 64, per = (T + nchunk - 1) / nchunk;
+    const long chunks = nslot * nchunk;
+    ZM_HIP_CHECK(hipFuncSetAttribute((const void*)quad_hessian_points_kernel<WIND, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL((quad_hessian_points_kernel<WIND, W>), dim3((unsigned)((chunks + W - 1) / W)), dim3(64 * W), bytes, st, md, xTraj,
+                       uTraj, active, Hs, T, list, nslot, per, nchunk);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
 int quad_hessian_sparse_list(const zm_model_t* model, const double* xTraj, const double* uTraj, const int32_t* list, int64_t count,
                              const int32_t* active, double* Hs, int64_t batch, int T, void* stream) {
     if (batch == 0 || count == 0) return ZM_OK;
@@ -689,6 +870,15 @@ int quad_hessian_sparse_list(const zm_model_t* model, const double* xTraj, const
     constexpr int PPB16 = 4 * LIN_WAVES;
     const long npts = (long)count * T;
     const dim3 grid16((unsigned)((npts + PPB16 - 1) / PPB16)), block16(64 * LIN_WAVES);
+    const bool windy = md.wind_ned[0] != 0.0 || md.wind_ned[1] != 0.0 || md.wind_ned[2] != 0.0;
+    static const bool by_points = [] {   // ZOPT_AMD_EXPAND=group: 16 lanes per point (A/B; same results)
+        const char* e = getenv("ZOPT_AMD_EXPAND");
+        return !(e && e[0] == 'g');
+    }();
+    if (by_points) {
+        if (windy) return launch_quad_hessian_points<true>(md, xTraj, uTraj, (const int*)active, Hs, T, (const int*)list, (long)count, (hipStream_t)stream);
+        return launch_quad_hessian_points<false>(md, xTraj, uTraj, (const int*)active, Hs, T, (const int*)list, (long)count, (hipStream_t)stream);
+    }
     if (md.wind_ned[0] != 0.0 || md.wind_ned[1] != 0.0 || md.wind_ned[2] != 0.0)
         hipLaunchKernelGGL((quad_hessian_pairs16_kernel<true, true>), grid16, block16, 0, (hipStream_t)stream, md, xTraj, uTraj,
                            (const int*)active, Hs, (long)batch, T, (const int*)list, (long)count);
