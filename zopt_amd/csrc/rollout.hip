@@ -262,7 +262,14 @@ __global__ __launch_bounds__(256) void ilqr_accept_kernel(const int* __restrict_
     // The mask is read ONCE per block and shared: thread 0 clears active[t] at the end of this same block, and a wave that
     // is scheduled late must not see that store and skip its stripe of the copy (a torn trajectory).
     __shared__ int act;
-    if (threadIdx.x == 0) act = active[t];   // the list may be older than the mask (it is rebuilt only every few iterations)
+    // (everything that depends on t alone leaves together with the mask's load: one memory round trip instead of three)
+    const int win = scratch ? idx[t] : 0;
+    double jn = 0.0, jo = 0.0;
+    if (threadIdx.x == 0) {
+        act = active[t];   // the list may be older than the mask (it is rebuilt only every few iterations)
+        jn = Jn[t];
+        jo = J[t];
+    }
     __syncthreads();
     if (act == 0) return;
     // the new trajectory: row t of (xT2, uT2), or -- after an all-store line search (n = 12, m = 4) -- the winner's 16-byte pieces
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(256) void ilqr_accept_kernel(const int* __restrict_
         // 16-byte pieces: (T + 1) * 6 of x, T * 2 of u
         constexpr int n = 12, m = 4, PB = (n + m) / 2;
         typedef double d2 __attribute__((ext_vector_type(2)));
-        const double* sb = scratch + slot * (xrow / n) * (PB * 32) + idx[t] * 2;
+        const double* sb = scratch + slot * (xrow / n) * (PB * 32) + win * 2;
         const long nxp = xrow / 2, nup = urow / 2;
         for (long e = threadIdx.x; e < nxp; e += blockDim.x) {
             const long k = e / (n / 2), p = e % (n / 2);
@@ -286,8 +293,7 @@ __global__ __launch_bounds__(256) void ilqr_accept_kernel(const int* __restrict_
         for (long e = threadIdx.x; e < urow; e += blockDim.x) uT[t * urow + e] = uT2[t * urow + e];
     }
     if (threadIdx.x == 0) {
-        const double jn = Jn[t];
-        const int cv = (__builtin_fabs(J[t] - jn) <= tol) ? 1 : 0;   // NaN compares false: never "converged"
+        const int cv = (__builtin_fabs(jo - jn) <= tol) ? 1 : 0;   // NaN compares false: never "converged"
         J[t] = jn;
         converged[t] = cv;
         active[t] = cv ? 0 : 1;
