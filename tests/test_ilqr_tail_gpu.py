@@ -75,6 +75,23 @@ def test_short_and_odd_horizons_agree_across_line_search_forms(N, tmp_path):
             assert np.array_equal(res[cases[0]][k], res[case][k], equal_nan=True), (N, case, k)
 
 
+@pytest.mark.parametrize("wind", ["still", "wind"])
+def test_horizon_of_three_uneven_chunks_agrees_across_expansion_forms(wind, tmp_path):
+    """The one-lane-per-point expansion kernels cut a trajectory into chunks of at most 64 points (T = 130: 44 + 44 + 42); the solve
+    equals the one with the 16-lanes-per-point kernels (ZOPT_AMD_EXPAND=group) bit for bit, second derivatives included (DDP), in
+    still air and with wind (the wind forms use three-wave workgroups)."""
+    res = {}
+    for form in ("points", "group"):
+        out = tmp_path / f"long_{wind}_{form}.npz"
+        p = subprocess.run([sys.executable, "-c", CHILD, str(out), "ddp", "130", wind], env=dict(os.environ, ZOPT_AMD_EXPAND=form),
+                           capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert p.returncode == 0 and "CHILD-OK" in p.stdout, (p.stdout[-300:], p.stderr[-1500:])
+        res[form] = dict(np.load(out))
+    assert res["points"]["c"].sum() > 0
+    for k in ("x", "u", "L", "J", "c"):
+        assert np.array_equal(res["points"][k], res["group"][k], equal_nan=True), (wind, k)
+
+
 @pytest.mark.parametrize("solver", ["ilqr", "ddp"])
 def test_windy_model_packed_and_full_operands_agree_and_match_the_oracle(solver, tmp_path):
     """A constant NED wind selects the wind forms of the generated derivatives (59 packed Jacobian entries, 85 sparse second derivatives)
