@@ -96,7 +96,7 @@ bool rollout_all_store_supported(const zm_model_t* model, const zm_quadcost_t* c
 int rollout_linesearch_all_store(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0, const double* l, const double* L,
                                  const double* xPrev, const double* uPrev, const double* alphas, const int32_t* list, int64_t count,
                                  const int32_t* active, double* scratch, double* J, int32_t* alpha_idx, int64_t batch, int T,
-                                 void* stream, const AcceptFuse* fuse, int* fused);
+                                 void* stream);
 int ilqr_accept(const int32_t* list, int64_t count, double* J, const double* Jn, double* xTraj, const double* xTrajNew, double* uTraj,
                 const double* uTrajNew, int32_t* converged, int32_t* active, double tol, int64_t batch, int T, int n, int m,
                 void* stream, const double* scratch, const int32_t* idx);
@@ -293,18 +293,10 @@ extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* c
         // 16-way line search (:116-150), then accept: converged = |J - J_new| <= tol, (traj, J) <- (traj_new, J_new) on the listed
         // rows (:316-320)
         if (can_all_store && count <= w.tail_slots) {
-            // (ZOPT_AMD_ACCEPT=own: the acceptance step always as its own launch; same results)
-            static const bool fuse_off = [] {
-                const char* e = getenv("ZOPT_AMD_ACCEPT");
-                return e && e[0] == 'o';
-            }();
-            const zm::AcceptFuse af{fuse_off ? nullptr : J, xTraj, uTraj, (int*)converged, (int*)active, tol};
-            int fused = 0;
             rc = zm::rollout_linesearch_all_store(model, cost, x0, ws + w.l, L, xTraj, uTraj, ws + w.alphas, list, count, active,
-                                                  ws + w.scratch, ws + w.Jn, widx, batch, T, st, &af, &fused);
+                                                  ws + w.scratch, ws + w.Jn, widx, batch, T, st);
             if (rc) return rc;
-            if (!fused)
-                rc = zm::ilqr_accept(list, count, J, ws + w.Jn, xTraj, nullptr, uTraj, nullptr, converged, active, tol, batch, T, n, m, st,
+            rc = zm::ilqr_accept(list, count, J, ws + w.Jn, xTraj, nullptr, uTraj, nullptr, converged, active, tol, batch, T, n, m, st,
                                  ws + w.scratch, widx);
         } else {
             rc = zm_rollout_linesearch_list_f64(model, cost, x0, ws + w.l, L, xTraj, uTraj, ws + w.alphas, 16, list, count, active,

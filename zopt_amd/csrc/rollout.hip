@@ -135,8 +135,7 @@ __global__ __launch_bounds__(64) void rollout_linesearch_kernel(const zm_model_t
 int rollout_fast_dispatch(const zm_model_t& md, const double* Q, const double* R, const double* Qf, int diagonal, const double* x0,
                           const double* l, const double* L, const double* xPrev, const double* uPrev,
                           const double* alphas, int n_alpha, const int* active, const int* list, int64_t count, double* xTraj,
-                          double* uTraj, double* J, int* idx, int64_t batch, int T, hipStream_t st, double* scratch, const AcceptFuse* fuse = nullptr,
-                          int* fused = nullptr);
+                          double* uTraj, double* J, int* idx, int64_t batch, int T, hipStream_t st, double* scratch);
 
 }  // namespace zm
 
@@ -144,9 +143,7 @@ static int rollout_impl(const zm_model_t* model, const zm_quadcost_t* cost, cons
                                          const double* l, const double* L, const double* xPrev, const double* uPrev,
                                          const double* alphas, int n_alpha, const int32_t* active, const int32_t* list,
                                          int64_t count, double* xTraj, double* uTraj, double* J, int32_t* alpha_idx,
-                                         int64_t batch, int T, void* stream, double* scratch = nullptr,
-                                         const zm::AcceptFuse* fuse = nullptr, int* fused = nullptr) {
-    if (fused) *fused = 0;
+                                         int64_t batch, int T, void* stream, double* scratch = nullptr) {
     if (!model || !x0 || !l || !L || !xPrev || !uPrev || !alphas || !xTraj || !uTraj)
         return zm::set_error(ZM_EINVAL, "zm_rollout_linesearch_f64: null pointer");
     if (batch < 0 || T < 0 || n_alpha < 1 || n_alpha > 16)
@@ -186,7 +183,7 @@ static int rollout_impl(const zm_model_t* model, const zm_quadcost_t* cost, cons
     //  redundant, and still several times faster than the generic lane-per-trajectory kernel with its uncoalesced policy reads)
     if (!force_generic && !windy && (n_alpha == 16 || n_alpha == 1) && md.n == 12 && md.m == 4 && cost && T >= 1)
         return zm::rollout_fast_dispatch(md, cs.Q, cs.R, cs.Qf, cs.diagonal, x0, l, L, xPrev, uPrev, alphas, n_alpha, act, (const int*)list, count, xTraj,
-                                         uTraj, J, (int*)alpha_idx, batch, T, st, scratch, fuse, fused);
+                                         uTraj, J, (int*)alpha_idx, batch, T, st, scratch);
     if (scratch) return zm::set_error(ZM_EUNSUPPORTED, "rollout: all-store mode needs the fast path");
     if (n_alpha == 1) {
         const unsigned blocks = (unsigned)((nslot + 63) / 64);
@@ -238,11 +235,10 @@ bool rollout_all_store_supported(const zm_model_t* model, const zm_quadcost_t* c
 int rollout_linesearch_all_store(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0, const double* l, const double* L,
                                  const double* xPrev, const double* uPrev, const double* alphas, const int32_t* list, int64_t count,
                                  const int32_t* active, double* scratch, double* J, int32_t* alpha_idx, int64_t batch, int T,
-                                 void* stream, const AcceptFuse* fuse, int* fused) {
+                                 void* stream) {
     // (xTraj / uTraj are not written in this mode; the non-null placeholders only pass the argument check)
-    // fuse: the caller's acceptance step, taken along when the one-trajectory-per-wave kernel runs (*fused = 1: done, skip ilqr_accept)
     return rollout_impl(model, cost, x0, l, L, xPrev, uPrev, alphas, 16, active, list, count, scratch, scratch, J, alpha_idx, batch, T,
-                        stream, scratch, fuse, fused);
+                        stream, scratch);
 }
 }  // namespace zm
 

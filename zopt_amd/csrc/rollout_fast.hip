@@ -360,7 +360,6 @@ struct QuadArgs {
     long batch;
     int T;
     double* scratch;
-    AcceptFuse acc;
 };
 int rollout_quad_all(const QuadArgs& g, hipStream_t st);
 int rollout_quad_reroll(const QuadArgs& g, hipStream_t st);
@@ -369,9 +368,7 @@ int rollout_quad_reroll(const QuadArgs& g, hipStream_t st);
 int rollout_fast_dispatch(const zm_model_t& md, const double* Q, const double* R, const double* Qf, int diagonal,
                           const double* x0, const double* l, const double* L, const double* xPrev, const double* uPrev,
                           const double* alphas, int n_alpha, const int* active, const int* list, int64_t count, double* xTraj,
-                          double* uTraj, double* J, int* idx, int64_t batch, int T, hipStream_t st, double* scratch, const AcceptFuse* fuse,
-                          int* fused) {
-    if (fused) *fused = 0;
+                          double* uTraj, double* J, int* idx, int64_t batch, int T, hipStream_t st, double* scratch) {
     FastArgs g{md.A, md.B, md.dt, Q, R, Qf, x0, l, L, xPrev, uPrev, alphas, active, list, (long)count, xTraj, uTraj, J, idx,
                (long)batch, T, n_alpha, scratch, 0};
     // ZOPT_AMD_ROLLOUT_QUAD=0: everything in rollout_ls_fast_kernel (A/B; same results)
@@ -380,8 +377,7 @@ int rollout_fast_dispatch(const zm_model_t& md, const double* Q, const double* R
         return !(e && e[0] == '0');
     }();
     const bool quad = quad_on && md.kind == ZM_MODEL_QUADCOPTER && diagonal == 1 && n_alpha == 16 && J && idx;
-    QuadArgs qa{md.dt, Q, R, Qf, x0, l, L, xPrev, uPrev, alphas, active, list, (long)count, xTraj, uTraj, J, idx, (long)batch, T, scratch,
-                AcceptFuse{nullptr, nullptr, nullptr, nullptr, nullptr, 0.0}};
+    const QuadArgs qa{md.dt, Q, R, Qf, x0, l, L, xPrev, uPrev, alphas, active, list, (long)count, xTraj, uTraj, J, idx, (long)batch, T, scratch};
     // all-store line search with at most one wave per SIMD: one trajectory per wave, 4 lanes per step size (78 against 104 us per
     // launch; four-wave workgroups so that up to 1024 waves each get a SIMD).  With more trajectories its 4x as many waves no longer
     // run alone and the 4-trajectories-per-wave kernel is faster (measured: 1131 trajectories 145 against ~125 us; iLQR solve with the
@@ -390,13 +386,7 @@ int rollout_fast_dispatch(const zm_model_t& md, const double* Q, const double* R
         const char* e = getenv("ZOPT_AMD_QUAD_ALL_MAX");
         return e ? atol(e) : 1024L;
     }();
-    if (quad && scratch && count <= quad_all_max) {
-        if (fuse && fuse->J) {   // the caller's acceptance step rides along (and the caller skips its own launch)
-            qa.acc = *fuse;
-            if (fused) *fused = 1;
-        }
-        return rollout_quad_all(qa, st);
-    }
+    if (quad && scratch && count <= quad_all_max) return rollout_quad_all(qa, st);
     if (quad && !scratch) g.no_pass2 = 1;                              // two-pass line search: the second pass as its own, densely packed launch
     int rc;
     if (md.kind == ZM_MODEL_QUADCOPTER) rc = launch_fast<ZM_MODEL_QUADCOPTER>(g, diagonal == 1, st);

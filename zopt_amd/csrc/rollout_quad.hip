@@ -31,7 +31,6 @@ struct QuadArgs {   // (declared identically in rollout_fast.hip, which decides 
     long batch;
     int T;
     double* scratch;            // all: the all-store blocks
-    AcceptFuse acc;             // all: fused acceptance step
 };
 
 // value of lane I of this lane's quad
@@ -169,31 +168,6 @@ __global__ __launch_bounds__(256) void rollout_quad_all_kernel(const QuadArgs g)
     if (lane == 0) {
         g.J[t] = Jbest;
         g.idx[t] = who;
-    }
-    if (g.acc.J) {
-        // ilqr_accept_kernel for this trajectory (rollout.hip): converged = |J - J_new| <= tol, (traj, J) <- (traj_new, J_new).  Only this
-        // wave touches trajectory t; its reads of xPrev / uPrev (= the rows overwritten here) are complete, and the fence makes the
-        // scratch stores of its other lanes visible to the gathers below.
-        __threadfence();
-        typedef double d2 __attribute__((ext_vector_type(2)));
-        const double* sb = g.scratch + slot * (long)(T + 1) * Q_ALLSTORE_BLOCK + who * 2;
-        double* xo = g.acc.xT + t * (long)(T + 1) * QN;
-        double* uo = g.acc.uT + t * (long)T * QM;
-        const int nxp = (T + 1) * (QN / 2), nup = T * (QM / 2);
-        for (int e = lane; e < nxp; e += 64) {
-            const int k = e / (QN / 2), p = e - k * (QN / 2);
-            *(d2*)(xo + 2 * e) = *(const d2*)(sb + ((long)k * (Q_ALLSTORE_BLOCK / 32) + p) * 32);
-        }
-        for (int e = lane; e < nup; e += 64) {
-            const int k = e / (QM / 2), p = e - k * (QM / 2);
-            *(d2*)(uo + 2 * e) = *(const d2*)(sb + ((long)(k + 1) * (Q_ALLSTORE_BLOCK / 32) + QN / 2 + p) * 32);
-        }
-        if (lane == 0) {
-            const int cv = (__builtin_fabs(g.acc.J[t] - Jbest) <= g.acc.tol) ? 1 : 0;   // NaN compares false: never "converged"
-            g.acc.J[t] = Jbest;
-            g.acc.converged[t] = cv;
-            g.acc.active[t] = cv ? 0 : 1;
-        }
     }
 }
 

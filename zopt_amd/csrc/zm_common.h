@@ -57,14 +57,4 @@ __device__ __forceinline__ double sum_xor32(const double v) {
     return x + y;
 }
 
-// Acceptance step fused into the one-trajectory-per-wave all-store line search (rollout_quad_all_kernel): the wave that rolled a
-// trajectory's 16 step sizes out also takes the winner over (ilqr_accept_kernel's work for that trajectory) -- one launch fewer per
-// iteration of the solvers' tail.  J == nullptr: no fusion.
-struct AcceptFuse {
-    double* J;          // current costs (compared with the line search's, then overwritten)
-    double *xT, *uT;    // current trajectories (overwritten with the winner's)
-    int *converged, *active;
-    double tol;
-};
-
 }  // namespace zm
