@@ -377,7 +377,7 @@ def run_rank(args):
     work.sync()
     # HIP events around single launches, on every `stride`-th step only: an event is a marker packet between two kernels, and a pair
     # around every launch costs the timed region ~3 us per step of its own (`value` is wall-clock over all K steps either way)
-    stride = 8 if args.steps >= 32 else 1
+    stride = 8 if args.steps >= 32 else (4 if args.steps >= 8 else 1)
     evs = {i: (work.event(), work.event()) for i in range(0, args.steps, stride)}
     barrier()
     work.sync()
