@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--T", type=int, default=100)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--ddp", action="store_true", help="differentialDynamicProgramming (R = 0.2 I as in its demo) instead of iterativeLqr")
+    ap.add_argument("--max-iter", type=int, default=100, help="maxIter of the solve (a few iterations: every launch at the full batch, for PMC runs)")
+    ap.add_argument("--no-warmup", action="store_true", help="skip the 64-trajectory warm-up solve (PMC means over one kernel's dispatches)")
     args = ap.parse_args()
     import torch
     from zopt_amd import ilqrUtils, models
@@ -30,12 +32,13 @@ def main():
     solve = ilqrUtils.differentialDynamicProgramming if args.ddp else ilqrUtils.iterativeLqr
     model = models.QuadcopterEuler(0.1)
     tx0, tug = torch.as_tensor(x0, device="cuda"), torch.as_tensor(ug, device="cuda")
-    solve(model, cost, cost, tx0[:64], tug[:64])       # warm-up
+    if not args.no_warmup:
+        solve(model, cost, cost, tx0[:64], tug[:64])       # warm-up
     torch.cuda.synchronize()
     times = []
     for _ in range(args.reps):
         t0 = time.perf_counter()
-        traj, L, J, conv = solve(model, cost, cost, tx0, tug)
+        traj, L, J, conv = solve(model, cost, cost, tx0, tug, maxIter=args.max_iter)
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
     t = min(times)
