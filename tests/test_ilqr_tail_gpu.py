@@ -76,8 +76,8 @@ def test_short_and_odd_horizons_agree_across_line_search_forms(N, tmp_path):
 
 
 @pytest.mark.parametrize("wind", ["still", "wind"])
-def test_horizon_of_three_uneven_chunks_agrees_across_expansion_forms(wind, tmp_path):
-    """The one-lane-per-point expansion kernels cut a trajectory into chunks of at most 64 points (T = 130: 44 + 44 + 42); the solve
+def test_horizon_of_several_chunks_agrees_across_expansion_forms(wind, tmp_path):
+    """The one-lane-per-point expansion kernels cut a trajectory into chunks of at most 32 points (T = 130: five chunks of 26); the solve
     equals the one with the 16-lanes-per-point kernels (ZOPT_AMD_EXPAND=group) bit for bit, second derivatives included (DDP), in
     still air and with wind (the wind forms use three-wave workgroups)."""
     res = {}

@@ -529,7 +529,7 @@ namespace zm {
 // lanes diverging over the columns -- every column's code for them: ~425 fp64 instructions per four points, which bound that launch
 // (0.30 ms per 8192 x 100 points where its stores need 0.1).  Here a lane evaluates the whole straight-line form of its point
 // (quad_jac_all_packed: the same temporaries and expressions, 119 operations in still air) into its row of a wave-private LDS tile,
-// and the wave then copies the tile out as the contiguous block it is in memory (a chunk = up to 64 consecutive points of one
+// and the wave then copies the tile out as the contiguous block it is in memory (a chunk = up to QP_R consecutive points of one
 // trajectory: NJP doubles per point for the Jacobians, 12 and 4 for the gradients).  Four waves per workgroup, no barrier.
 // copy-out of a wave's LDS tile: `tot` consecutive doubles of the output block, element e from row e / ROW, column COL0 + e % ROW of
 // the tile; eight independent LDS reads in flight per lane before their stores
@@ -552,6 +552,14 @@ __device__ __forceinline__ void tile_copy_out(double* __restrict__ op, const dou
 }
 
 constexpr int QP_WAVES = 4;
+#ifndef QP_ROWS
+#define QP_ROWS 32
+#endif
+// Points per chunk = rows of a wave's LDS tile.  64 (every lane a point) leaves one wave per SIMD (37 KB of LDS per wave) and the launch
+// waits on its loads and stores half of its time; with 32 or 16 the idle lanes cost little (the arithmetic is ~25 % of a wave's life at 50
+// points) and two to four times as many waves overlap: expansion at the full batch 133-142 / 128-132 / 122-127 us for 64 / 32 / 16 rows.
+// 32: the wind forms carry twice the arithmetic.
+constexpr int QP_R = QP_ROWS;
 template <bool WIND>
 __global__ __launch_bounds__(64 * QP_WAVES) void expand_quad_points_kernel(const zm_model_t md, const double* __restrict__ xTraj,
                                                                            const double* __restrict__ uTraj,
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(64 * QP_WAVES) void expand_quad_points_kernel(const
     constexpr int LD = NJP + 16 + 1;   // a point's row: packed Jacobians, c_x, c_u; odd, so that the lanes' rows start in different banks
     extern __shared__ __attribute__((aligned(16))) double qp_lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    double* tile = qp_lds + (long)wv * 64 * LD;
+    double* tile = qp_lds + (long)wv * QP_R * LD;
     const long chunk = (long)blockIdx.x * QP_WAVES + wv;
     if (chunk >= nslot * nchunk) return;
     const long slot = chunk / nchunk;
@@ -635,9 +643,9 @@ template <bool WIND>
 static int launch_expand_quad_points(const zm_model_t& md, const double* xTraj, const double* uTraj, const int* active, double* f_x,
                                      const int T, const int* list, const long nslot, const ExpandCost& ec, hipStream_t st) {
     constexpr int NJ = WIND ? QUAD_NJ_WIND : QUAD_NJ_STILL, NJP = (NJ + 1) & ~1, LD = NJP + 16 + 1;
-    const size_t bytes = (size_t)QP_WAVES * 64 * LD * sizeof(double);
-    static_assert((size_t)QP_WAVES * 64 * (((QUAD_NJ_WIND + 1) & ~1) + 17) * sizeof(double) <= 160 * 1024, "LDS tile of four waves");
-    const int nchunk = (T + 63) / 64, per = (T + nchunk - 1) / nchunk;
+    const size_t bytes = (size_t)QP_WAVES * QP_R * LD * sizeof(double);
+    static_assert((size_t)QP_WAVES * QP_R * (((QUAD_NJ_WIND + 1) & ~1) + 17) * sizeof(double) <= 160 * 1024, "LDS tile of four waves");
+    const int nchunk = (T + QP_R - 1) / QP_R, per = (T + nchunk - 1) / nchunk;
     const long chunks = nslot * nchunk;
     // per launch (cheap): the attribute is per device, and several devices may be driven from one process
     ZM_HIP_CHECK(hipFuncSetAttribute((const void*)expand_quad_points_kernel<WIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -824,7 +832,7 @@ __global__ __launch_bounds__(64 * W) void quad_hessian_points_kernel(const zm_mo
     constexpr int NH = WIND ? QUAD_NH_WIND : QUAD_NH_STILL, NHP = (NH + 1) & ~1, LD = NHP + 1;
     extern __shared__ __attribute__((aligned(16))) double qp_lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    double* tile = qp_lds + (long)wv * 64 * LD;
+    double* tile = qp_lds + (long)wv * QP_R * LD;
     const long chunk = (long)blockIdx.x * W + wv;
     if (chunk >= nslot * nchunk) return;
     const long slot = chunk / nchunk;
@@ -848,10 +856,10 @@ template <bool WIND>
 static int launch_quad_hessian_points(const zm_model_t& md, const double* xTraj, const double* uTraj, const int* active, double* Hs,
                                       const int T, const int* list, const long nslot, hipStream_t st) {
     constexpr int NH = WIND ? QUAD_NH_WIND : QUAD_NH_STILL, NHP = (NH + 1) & ~1, LD = NHP + 1;
-    constexpr int W = (4 * 64 * LD * 8 <= 160 * 1024) ? 4 : 3;
-    static_assert(W * 64 * LD * 8 <= 160 * 1024, "LDS tile of the workgroup");
-    const size_t bytes = (size_t)W * 64 * LD * sizeof(double);
-    const int nchunk = (T + 63) / 64, per = (T + nchunk - 1) / nchunk;
+    constexpr int W = (4 * QP_R * LD * 8 <= 160 * 1024) ? 4 : 3;
+    static_assert(W * QP_R * LD * 8 <= 160 * 1024, "LDS tile of the workgroup");
+    const size_t bytes = (size_t)W * QP_R * LD * sizeof(double);
+    const int nchunk = (T + QP_R - 1) / QP_R, per = (T + nchunk - 1) / nchunk;
     const long chunks = nslot * nchunk;
     ZM_HIP_CHECK(hipFuncSetAttribute((const void*)quad_hessian_points_kernel<WIND, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     hipLaunchKernelGGL((quad_hessian_points_kernel<WIND, W>), dim3((unsigned)((chunks + W - 1) / W)), dim3(64 * W), bytes, st, md, xTraj,
