@@ -77,13 +77,13 @@ def test_short_and_odd_horizons_agree_across_line_search_forms(N, tmp_path):
 
 @pytest.mark.parametrize("wind", ["still", "wind"])
 def test_horizon_of_several_chunks_agrees_across_expansion_forms(wind, tmp_path):
-    """The one-lane-per-point expansion kernels cut a trajectory into chunks of at most 32 points (T = 130: five chunks of 26); the solve
+    """The one-lane-per-point expansion kernels cut a trajectory into chunks of at most 32 points (T = 131: four chunks of 27 and one of 23); the solve
     equals the one with the 16-lanes-per-point kernels (ZOPT_AMD_EXPAND=group) bit for bit, second derivatives included (DDP), in
     still air and with wind (the wind forms use three-wave workgroups)."""
     res = {}
     for form in ("points", "group"):
         out = tmp_path / f"long_{wind}_{form}.npz"
-        p = subprocess.run([sys.executable, "-c", CHILD, str(out), "ddp", "130", wind], env=dict(os.environ, ZOPT_AMD_EXPAND=form),
+        p = subprocess.run([sys.executable, "-c", CHILD, str(out), "ddp", "131", wind], env=dict(os.environ, ZOPT_AMD_EXPAND=form),
                            capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert p.returncode == 0 and "CHILD-OK" in p.stdout, (p.stdout[-300:], p.stderr[-1500:])
         res[form] = dict(np.load(out))
