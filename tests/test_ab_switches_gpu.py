@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SWITCHES = [{}, {"ZOPT_AMD_LQR_G4": "0"}, {"ZOPT_AMD_LQR_D": "2"}, {"ZOPT_AMD_LQR_PATH": "lds"}, {"ZOPT_AMD_ILQR_PATH": "reg"},
             {"ZOPT_AMD_ROLLOUT_PATH": "generic"}, {"ZOPT_AMD_ILQR_SYNC": "1"}, {"ZOPT_AMD_ILQR_SYNC": "0"},   # 0 is clamped to 1
-            {"ZOPT_AMD_ILQR_SYNC": "7"}, {"ZOPT_AMD_MPC_PATH": "lane"}, {"ZOPT_AMD_ILQR_TAIL": "0"}, {"ZOPT_AMD_ILQR_TAIL": "2"}, {"ZOPT_AMD_ROLLOUT_QUAD": "0"}, {"ZOPT_AMD_QUAD_ALL_MAX": "3"}, {"ZOPT_AMD_EXPAND": "group"}, {"ZOPT_AMD_LQR_F32": "tile"}, {"ZOPT_AMD_JAC": "full"}, {"ZOPT_AMD_HES": "dense"}]
+            {"ZOPT_AMD_ILQR_SYNC": "7"}, {"ZOPT_AMD_MPC_PATH": "lane"}, {"ZOPT_AMD_ILQR_TAIL": "0"}, {"ZOPT_AMD_ILQR_TAIL": "2"}, {"ZOPT_AMD_ROLLOUT_QUAD": "0"}, {"ZOPT_AMD_QUAD_ALL_MAX": "3"}, {"ZOPT_AMD_EXPAND": "group"}, {"ZOPT_AMD_ILQR_SWAP": "0"}, {"ZOPT_AMD_LQR_F32": "tile"}, {"ZOPT_AMD_JAC": "full"}, {"ZOPT_AMD_HES": "dense"}]
 
 
 @pytest.mark.parametrize("env", SWITCHES, ids=[",".join(f"{k}={v}" for k, v in e.items()) or "defaults" for e in SWITCHES])

@@ -38,14 +38,16 @@ def test_solve_is_bit_identical_for_every_tail_threshold(solver, tmp_path):
     # never / from the first iteration / switches when 40 of the 96 are left; the same without the quad kernels
     # (the last case also with the full instead of the packed Jacobians between the expansion and the sweep: ZOPT_AMD_JAC=full; the
     # cases without the quad kernels also with the dense instead of the sparse second derivatives: ZOPT_AMD_HES=dense)
-    # (and one case with the 16-lanes-per-point expansion kernels instead of the one-lane-per-point ones: ZOPT_AMD_EXPAND=group)
+    # (and one case with the 16-lanes-per-point expansion kernels instead of the one-lane-per-point ones: ZOPT_AMD_EXPAND=group; two with
+    # the acceptance step copying the new trajectories instead of the solve alternating between two buffers: ZOPT_AMD_ILQR_SWAP=0)
     cases = [("0", "1", "packed"), ("1000000", "1", "packed"), ("40", "1", "packed"), ("0", "0", "packed"), ("1000000", "0", "packed"),
-             ("40", "0", "full"), ("40", "1", "packed-group")]
+             ("40", "0", "full"), ("40", "1", "packed-group"), ("40", "1", "packed-copy"), ("0", "0", "packed-copy")]
     for thr, quad, jac in cases:
         out = tmp_path / f"{solver}_{thr}_{quad}_{jac}.npz"
         p = subprocess.run([sys.executable, "-c", CHILD, str(out), solver],
                            env=dict(os.environ, ZOPT_AMD_ILQR_TAIL=thr, ZOPT_AMD_ROLLOUT_QUAD=quad, ZOPT_AMD_JAC=jac.split("-")[0],
                                     ZOPT_AMD_EXPAND="group" if jac.endswith("group") else "points",
+                                    ZOPT_AMD_ILQR_SWAP="0" if jac.endswith("copy") else "1",
                                     ZOPT_AMD_HES="dense" if quad == "0" else "sparse"), capture_output=True,
                            text=True, timeout=600, cwd=ROOT)
         assert p.returncode == 0 and "CHILD-OK" in p.stdout, (p.stdout[-300:], p.stderr[-1500:])

@@ -9,6 +9,7 @@
 // device every `sync_every` iterations, when the host also learns how many are left), converged trajectories drop out.
 // The kernels are the ones behind the array-level entry points (linearize.hip, ilqr_backward.hip, rollout*.hip, psd.hip);
 // nothing is allocated here: the caller provides the workspace (zm_ilqr_solve_workspace_f64 tells how much).
+#include <utility>
 #include <cstdint>
 #include <cstdlib>
 
@@ -62,7 +63,7 @@ __global__ void fill_f64_kernel(double* __restrict__ p, const long n, const doub
 }
 
 struct IlqrWs {   // carve of the caller's workspace (doubles)
-    long l, xT2, uT2, Jn, f_x, f_u, c_x, c_u, v_x, c_xx, c_ux, c_uu, v_xx, alphas, f_xx, f_ux, f_uu, idx, scratch, tail_slots, total;
+    long l, xT2, uT2, Jn, f_x, f_u, c_x, c_u, v_x, c_xx, c_ux, c_uu, v_xx, alphas, f_xx, f_ux, f_uu, idx, where, scratch, tail_slots, total;
 };
 
 // Once at most this many trajectories are left, the line search runs in all-store mode (rollout_fast.hip): its 16 rollouts per
@@ -99,7 +100,9 @@ int rollout_linesearch_all_store(const zm_model_t* model, const zm_quadcost_t* c
                                  void* stream);
 int ilqr_accept(const int32_t* list, int64_t count, double* J, const double* Jn, double* xTraj, const double* xTrajNew, double* uTraj,
                 const double* uTrajNew, int32_t* converged, int32_t* active, double tol, int64_t batch, int T, int n, int m,
-                void* stream, const double* scratch, const int32_t* idx);
+                void* stream, const double* scratch, const int32_t* idx, int32_t* where, int where_val);
+int ilqr_collect(const int32_t* where, double* xTraj, const double* xAlt, double* uTraj, const double* uAlt, int64_t batch, int T, int n,
+                 int m, void* stream);
 
 static IlqrWs carve(long b, long T, long n, long m, int ddp, int need_ux, int npairs) {
     IlqrWs w;
@@ -128,6 +131,7 @@ static IlqrWs carve(long b, long T, long n, long m, int ddp, int need_ux, int np
     w.f_ux = (ddp && need_ux && npairs == 0) ? take(b * T * n * m * n) : 0;
     w.f_uu = (ddp && need_ux && npairs == 0) ? take(b * T * n * m * m) : 0;
     w.idx = take((b + 1) / 2);   // int32 winner index per trajectory
+    w.where = take((b + 1) / 2); // int32 per trajectory: 0 = newest rows in the caller's xTraj / uTraj, 1 = in xT2 / uT2
     w.tail_slots = ilqr_tail_slots(b);
     w.scratch = take(w.tail_slots * (T + 1) * 256);   // all-store blocks (n = 12, m = 4 only): 16 step sizes x 16 doubles per step
     w.total = o;
@@ -235,6 +239,18 @@ extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* c
     }
     int32_t* const hcount_pinned = words[dev];
     const hipEvent_t count_ready = events[dev];
+    // The trajectories alternate between two buffers: the two-pass line search reads the current rows (xPrev, uPrev) and writes the
+    // winner's into the other buffer, which then IS the current one -- the acceptance step copies nothing (it was 212 MB per
+    // full-batch iteration).  Every active trajectory is rewritten in every iteration, so the current buffer is the same for all of
+    // them; a trajectory that retires stays where it was last written (`where`), and the rows left in the workspace buffer move to
+    // the caller's arrays once, at the end.  (ZOPT_AMD_ILQR_SWAP=0: the acceptance step copies, as before; same results.)
+    static const bool swap_on = [] {
+        const char* e = getenv("ZOPT_AMD_ILQR_SWAP");
+        return !(e && e[0] == '0');
+    }();
+    int32_t* where = (int32_t*)(ws + w.where);
+    if (swap_on) ZM_HIP_CHECK(hipMemsetAsync(where, 0, sizeof(int32_t) * batch, st));
+    double *curX = xTraj, *curU = uTraj, *altX = ws + w.xT2, *altU = ws + w.uT2;
     int it = 0;
     int64_t count = batch;
     for (; it < max_iter; ++it) {                                                                        // (:301-303)
@@ -251,7 +267,7 @@ extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* c
             ZM_HIP_CHECK(hipEventRecord(count_ready, st));
         }
         // expansions along the current trajectories: [f_x | f_u], c_x, c_u, v_x in one launch                  (:304-313)
-        rc = zm::expand_list(model, cost, xTraj, uTraj, list, count, active, ws + w.f_x, ws + w.f_u, ws + w.c_x, ws + w.c_u,
+        rc = zm::expand_list(model, cost, curX, curU, list, count, active, ws + w.f_x, ws + w.f_u, ws + w.c_x, ws + w.c_u,
                              ws + w.v_x, batch, T, st, packed ? 1 : 0);
         if (rc) return rc;
         if (sync_now) {
@@ -261,10 +277,10 @@ extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* c
         }
         if (packed) {
             if (sparse_h) {
-                rc = zm::quad_hessian_sparse_list(model, xTraj, uTraj, list, count, active, ws + w.f_xx, batch, T, st);
+                rc = zm::quad_hessian_sparse_list(model, curX, curU, list, count, active, ws + w.f_xx, batch, T, st);
                 if (rc) return rc;
             } else if (ddp) {
-                rc = zm_quadratic_dynamics_pairs_list_f64(model, xTraj, uTraj, list, count, active, ws + w.f_xx, batch, T, st);
+                rc = zm_quadratic_dynamics_pairs_list_f64(model, curX, curU, list, count, active, ws + w.f_xx, batch, T, st);
                 if (rc) return rc;
             }
             rc = zm::sweep_packed_jacobians(ws + w.f_x, njp, jpos, ddp ? ws + w.f_xx : nullptr, ptab, ws + w.c_x, ws + w.c_u, ws + w.c_xx,
@@ -274,13 +290,13 @@ extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* c
         } else if (ddp && npairs > 0) {
             // packed second derivatives: 28 x 12 doubles per point for the quadcopter instead of the zero-filled (n,n,n) tensors
             // (2.7 KB instead of 13.8 KB written by the expansion and read back by the sweep, same arithmetic)
-            rc = zm_quadratic_dynamics_pairs_list_f64(model, xTraj, uTraj, list, count, active, ws + w.f_xx, batch, T, st);
+            rc = zm_quadratic_dynamics_pairs_list_f64(model, curX, curU, list, count, active, ws + w.f_xx, batch, T, st);
             if (rc) return rc;
             rc = zm_ddp_backward_pairs_list_f64(model, ws + w.f_x, ws + w.f_u, ws + w.f_xx, ws + w.c_x, ws + w.c_u, ws + w.c_xx,
                                                 ws + w.c_ux, ws + w.c_uu, ws + w.v_x, ws + w.v_xx, list, count, active, 1, ws + w.l,
                                                 L, batch, T, st);
         } else if (ddp) {
-            rc = zm_quadratic_dynamics_list_f64(model, xTraj, uTraj, list, count, active, ws + w.f_xx, f_ux, f_uu, batch, T, st);
+            rc = zm_quadratic_dynamics_list_f64(model, curX, curU, list, count, active, ws + w.f_xx, f_ux, f_uu, batch, T, st);
             if (rc) return rc;
             rc = zm_ddp_backward_list_f64(ws + w.f_x, ws + w.f_u, ws + w.f_xx, f_ux, f_uu, ws + w.c_x, ws + w.c_u, ws + w.c_xx,
                                           ws + w.c_ux, ws + w.c_uu, ws + w.v_x, ws + w.v_xx, list, count, active, 1, ws + w.l, L,
@@ -293,11 +309,19 @@ extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* c
         // 16-way line search (:116-150), then accept: converged = |J - J_new| <= tol, (traj, J) <- (traj_new, J_new) on the listed
         // rows (:316-320)
         if (can_all_store && count <= w.tail_slots) {
-            rc = zm::rollout_linesearch_all_store(model, cost, x0, ws + w.l, L, xTraj, uTraj, ws + w.alphas, list, count, active,
+            rc = zm::rollout_linesearch_all_store(model, cost, x0, ws + w.l, L, curX, curU, ws + w.alphas, list, count, active,
                                                   ws + w.scratch, ws + w.Jn, widx, batch, T, st);
             if (rc) return rc;
-            rc = zm::ilqr_accept(list, count, J, ws + w.Jn, xTraj, nullptr, uTraj, nullptr, converged, active, tol, batch, T, n, m, st,
-                                 ws + w.scratch, widx);
+            rc = zm::ilqr_accept(list, count, J, ws + w.Jn, curX, nullptr, curU, nullptr, converged, active, tol, batch, T, n, m, st,
+                                 ws + w.scratch, widx, swap_on ? where : nullptr, curX == xTraj ? 0 : 1);
+        } else if (swap_on) {
+            rc = zm_rollout_linesearch_list_f64(model, cost, x0, ws + w.l, L, curX, curU, ws + w.alphas, 16, list, count, active, altX,
+                                                altU, ws + w.Jn, widx, batch, T, st);
+            if (rc) return rc;
+            rc = zm::ilqr_accept(list, count, J, ws + w.Jn, altX, nullptr, altU, nullptr, converged, active, tol, batch, T, n, m, st,
+                                 nullptr, nullptr, where, altX == xTraj ? 0 : 1);
+            std::swap(curX, altX);
+            std::swap(curU, altU);
         } else {
             rc = zm_rollout_linesearch_list_f64(model, cost, x0, ws + w.l, L, xTraj, uTraj, ws + w.alphas, 16, list, count, active,
                                                 ws + w.xT2, ws + w.uT2, ws + w.Jn, widx, batch, T, st);
@@ -305,6 +329,10 @@ extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* c
             rc = zm_ilqr_accept_f64(list, count, J, ws + w.Jn, xTraj, ws + w.xT2, uTraj, ws + w.uT2, converged, active, tol, batch, T,
                                     n, m, st);
         }
+        if (rc) return rc;
+    }
+    if (swap_on) {
+        rc = zm::ilqr_collect(where, xTraj, ws + w.xT2, uTraj, ws + w.uT2, batch, T, n, m, st);
         if (rc) return rc;
     }
     if (iterations) *iterations = it;

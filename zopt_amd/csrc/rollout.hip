@@ -255,7 +255,8 @@ __global__ __launch_bounds__(256) void ilqr_accept_kernel(const int* __restrict_
                                                           double* __restrict__ uT, const double* __restrict__ uT2,
                                                           int* __restrict__ converged, int* __restrict__ active,
                                                           const double tol, const long xrow, const long urow,
-                                                          const double* __restrict__ scratch, const int* __restrict__ idx) {
+                                                          const double* __restrict__ scratch, const int* __restrict__ idx,
+                                                          int* __restrict__ where, const int where_val) {
     const long slot = blockIdx.x;
     if (slot >= count) return;
     const long t = list[slot];
@@ -288,11 +289,12 @@ __global__ __launch_bounds__(256) void ilqr_accept_kernel(const int* __restrict_
             const long k = e / (m / 2), p = e % (m / 2);
             *(d2*)(uT + t * urow + 2 * e) = *(const d2*)(sb + ((k + 1) * PB + n / 2 + p) * 32);
         }
-    } else {
+    } else if (xT2) {
         for (long e = threadIdx.x; e < xrow; e += blockDim.x) xT[t * xrow + e] = xT2[t * xrow + e];
         for (long e = threadIdx.x; e < urow; e += blockDim.x) uT[t * urow + e] = uT2[t * urow + e];
-    }
+    }   // (else: the line search wrote the new rows where the caller wants them -- the solvers' alternating buffers)
     if (threadIdx.x == 0) {
+        if (where) where[t] = where_val;   // which of the solver's two buffers holds this trajectory's newest rows
         const int cv = (__builtin_fabs(jo - jn) <= tol) ? 1 : 0;   // NaN compares false: never "converged"
         J[t] = jn;
         converged[t] = cv;
@@ -304,15 +306,35 @@ __global__ __launch_bounds__(256) void ilqr_accept_kernel(const int* __restrict_
 namespace zm {
 int ilqr_accept(const int32_t* list, int64_t count, double* J, const double* Jn, double* xTraj, const double* xTrajNew, double* uTraj,
                 const double* uTrajNew, int32_t* converged, int32_t* active, double tol, int64_t batch, int T, int n, int m,
-                void* stream, const double* scratch, const int32_t* idx) {
+                void* stream, const double* scratch, const int32_t* idx, int32_t* where, int where_val) {
     if (batch == 0 || count == 0) return ZM_OK;
-    if (!list || !J || !Jn || !xTraj || !uTraj || !converged || !active || (scratch ? !idx : (!xTrajNew || !uTrajNew)))
+    // (where != nullptr and no scratch: xTrajNew / uTrajNew may be nullptr -- nothing to copy, the new rows are in place)
+    if (!list || !J || !Jn || !xTraj || !uTraj || !converged || !active || (scratch ? !idx : (!where && (!xTrajNew || !uTrajNew))))
         return set_error(ZM_EINVAL, "zm_ilqr_accept_f64: null pointer");
     if (count < 0 || count > batch || T < 1 || n < 1 || m < 1) return set_error(ZM_EINVAL, "zm_ilqr_accept_f64: bad size");
     if (scratch && (n != 12 || m != 4)) return set_error(ZM_EUNSUPPORTED, "ilqr_accept: all-store scratch is laid out for n = 12, m = 4");
     hipLaunchKernelGGL(ilqr_accept_kernel, dim3((unsigned)count), dim3(256), 0, (hipStream_t)stream, (const int*)list,
                        (long)count, J, Jn, xTraj, xTrajNew, uTraj, uTrajNew, (int*)converged, (int*)active, tol,
-                       (long)(T + 1) * n, (long)T * m, scratch, (const int*)idx);
+                       (long)(T + 1) * n, (long)T * m, scratch, (const int*)idx, (int*)where, where_val);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+
+// End of a solve on alternating buffers: the rows of every trajectory whose newest state sits in the workspace buffer (where[t] != 0)
+// move to the caller's arrays.  One block per trajectory.
+__global__ __launch_bounds__(256) void ilqr_collect_kernel(const int* __restrict__ where, double* __restrict__ xT,
+                                                           const double* __restrict__ xAlt, double* __restrict__ uT,
+                                                           const double* __restrict__ uAlt, const long xrow, const long urow) {
+    const long t = blockIdx.x;
+    if (where[t] == 0) return;
+    for (long e = threadIdx.x; e < xrow; e += blockDim.x) xT[t * xrow + e] = xAlt[t * xrow + e];
+    for (long e = threadIdx.x; e < urow; e += blockDim.x) uT[t * urow + e] = uAlt[t * urow + e];
+}
+int ilqr_collect(const int32_t* where, double* xTraj, const double* xAlt, double* uTraj, const double* uAlt, int64_t batch, int T, int n,
+                 int m, void* stream) {
+    if (batch == 0) return ZM_OK;
+    hipLaunchKernelGGL(ilqr_collect_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, (const int*)where, xTraj, xAlt,
+                       uTraj, uAlt, (long)(T + 1) * n, (long)T * m);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }
@@ -322,5 +344,5 @@ extern "C" int zm_ilqr_accept_f64(const int32_t* list, int64_t count, double* J,
                                   const double* xTrajNew, double* uTraj, const double* uTrajNew, int32_t* converged,
                                   int32_t* active, double tol, int64_t batch, int T, int n, int m, void* stream) {
     return zm::ilqr_accept(list, count, J, Jn, xTraj, xTrajNew, uTraj, uTrajNew, converged, active, tol, batch, T, n, m, stream,
-                           nullptr, nullptr);
+                           nullptr, nullptr, nullptr, 0);
 }
