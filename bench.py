@@ -258,6 +258,20 @@ def usable_cores():
     return n
 
 
+def host_cpu():
+    """Model name and logical CPU count of the host (printed next to the CPU baselines), from /proc/cpuinfo"""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"model": model, "logical_cpus": os.cpu_count(), "numpy": np.__version__}
+
+
 def cpu_baseline(batch, T, n, m, target_seconds=10.0):
     """Times the plain-C oracle (a port of lqrUtils.py:167-172) on all host cores over the same workload."""
     from oracle import c_oracle
@@ -278,7 +292,7 @@ def cpu_baseline(batch, T, n, m, target_seconds=10.0):
             break
     return {"value": batch * T * reps / elapsed, "unit": "horizon-steps/s", "cores": cores, "kind": "port",
             "sample": f"full workload ({batch} trajectories x T={T}, n={n}, m={m}, fp64) x {reps} reps, "
-                      f"oracle/riccati_oracle.c with OpenMP over the batch"}
+                      f"oracle/riccati_oracle.c with OpenMP over the batch", "host": host_cpu()}
 
 
 def cpu_baseline_numpy(batch, T, n, m, target_seconds=4.0):
