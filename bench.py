@@ -269,7 +269,8 @@ def host_cpu():
                     break
     except OSError:
         pass
-    return {"model": model, "logical_cpus": os.cpu_count(), "numpy": np.__version__}
+    import numpy
+    return {"model": model, "logical_cpus": os.cpu_count(), "numpy": numpy.__version__}
 
 
 def cpu_baseline(batch, T, n, m, target_seconds=10.0):
