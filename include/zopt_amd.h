@@ -397,6 +397,15 @@ int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* cost, const 
                       int max_iter, double tol, int sync_every, double* workspace, int64_t workspace_doubles, int32_t* iwork,
                       double* xTraj, double* uTraj, double* L, double* J, int32_t* converged, int32_t* iterations, int64_t batch,
                       int T, void* stream);
+/* The same solve with a per-iteration record (diagnostics; the parity tests compare it with the oracle loop iteration by
+ * iteration, zopt/ilqrUtils.py:305-322): J_trace (max_iter, batch) [device, may be NULL]: row i <- every trajectory's cost after
+ * iteration i's acceptance step (`J_new` of :316-320; the cost it retired with once it has converged); alpha_trace (max_iter, batch)
+ * int32 [device, may be NULL]: row i <- index into 0.5**arange(16) of the step size forwardPass2's argmin picked (:145-149),
+ * meaningful for the trajectories that were still active in iteration i.  Rows >= *iterations are not written. */
+int zm_ilqr_solve_trace_f64(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0, const double* uGuess, int ddp,
+                            int max_iter, double tol, int sync_every, double* workspace, int64_t workspace_doubles, int32_t* iwork,
+                            double* xTraj, double* uTraj, double* L, double* J, int32_t* converged, int32_t* iterations,
+                            int64_t batch, int T, void* stream, double* J_trace, int32_t* alpha_trace);
 
 /* Same, with OSQP's over-relaxation `alpha` in (0, 2) (OSQP / cvxpy default 1.6, which is what the reference's
  * `prob.solve(**kwargs)` runs with, mpcUtils.py:77): the relaxed iterate alpha w + (1 - alpha) y_prev enters the projection and

@@ -323,14 +323,17 @@ def trajectoryCost(runningCost: Callable, terminalCost: Callable, traj: Trajecto
 LINESEARCH_ALPHAS = 0.5 ** np.arange(16)       # ilqrUtils.py:145
 
 
-def forwardPass2(x0, dynFun, runningCost, terminalCost, policy, trajPrev):
-    """16 rollouts at alpha = 0.5**j, take argmin of J (NaN wins, as in NumPy/JAX argmin)."""
+def forwardPass2(x0, dynFun, runningCost, terminalCost, policy, trajPrev, return_index=False):
+    """16 rollouts at alpha = 0.5**j, take argmin of J (NaN wins, as in NumPy/JAX argmin).
+    `return_index` (test diagnostics): also the winning index into LINESEARCH_ALPHAS and all 16 costs."""
     Js, trajs = [], []
     for alpha in LINESEARCH_ALPHAS:
         t = trajectoryRollout(x0, dynFun, policy, trajPrev, alpha=alpha)
         trajs.append(t)
         Js.append(trajectoryCost(runningCost, terminalCost, t))
     idx = int(np.argmin(np.asarray(Js)))
+    if return_index:
+        return trajs[idx], Js[idx], idx, np.asarray(Js)
     return trajs[idx], Js[idx]
 
 
@@ -458,9 +461,10 @@ def terminal_value_function(Qf, xf) -> QuadraticValueFunction:
 # ----------------------------------------------------------------------------------------
 # A8  iterativeLqr                                         reference ilqrUtils.py:260-327
 # ----------------------------------------------------------------------------------------
-def iterativeLqr(dynFun, Q, R, Qf, x0, uGuess, maxIter=100, tol=1e-3, return_iters=False):
+def iterativeLqr(dynFun, Q, R, Qf, x0, uGuess, maxIter=100, tol=1e-3, return_iters=False, trace=None):
     """iLQR loop of ilqrUtils.py:290-327 for an analytic `dynFun` and the quadratic cost (Q, R, Qf).
-    Returns (Trajectory, L (N,m,n), J, converged)."""
+    Returns (Trajectory, L (N,m,n), J, converged).  `trace` (a list, test diagnostics): receives per iteration
+    (J_new, winning step-size index, the 16 costs of the line search)."""
     Q, R, Qf = (np.asarray(t, dtype=np.float64) for t in (Q, R, Qf))
     x0 = np.asarray(x0, dtype=np.float64)
     uGuess = np.asarray(uGuess, dtype=np.float64)
@@ -479,7 +483,9 @@ def iterativeLqr(dynFun, Q, R, Qf, x0, uGuess, maxIter=100, tol=1e-3, return_ite
         cost = conditionQuadraticCost(cost)                                               # :312
         Vf = conditionValueFunction(Vf)                                                   # :313
         policy = backwardPass_ilqr(dyn, cost, Vf)                                         # :315
-        traj_new, J_new = forwardPass2(x0, dynFun, runningCost, terminalCost, policy, traj)   # :316
+        traj_new, J_new, idx, Js = forwardPass2(x0, dynFun, runningCost, terminalCost, policy, traj, return_index=True)   # :316
+        if trace is not None:
+            trace.append((J_new, idx, Js))
         converged = bool(abs(J - J_new) <= tol)                                           # :318
         traj, J = traj_new, J_new
         it += 1
@@ -540,7 +546,7 @@ def quadratic_dynamics_from_trajectory(f_torch, traj: Trajectory) -> QuadraticDy
 # ----------------------------------------------------------------------------------------
 # A8 (DDP) differentialDynamicProgramming                 reference ilqrUtils.py:330-397
 # ----------------------------------------------------------------------------------------
-def differentialDynamicProgramming(dynFun, f_torch, Q, R, Qf, x0, uGuess, maxIter=100, tol=1e-3, return_iters=False):
+def differentialDynamicProgramming(dynFun, f_torch, Q, R, Qf, x0, uGuess, maxIter=100, tol=1e-3, return_iters=False, trace=None):
     """DDP loop of ilqrUtils.py:360-397: as iterativeLqr with QuadraticDynamics (:365) and backwardPass_ddp (:373).
     `dynFun` (NumPy) rolls out, `f_torch` (the same map in torch) supplies the first and second derivatives."""
     Q, R, Qf = (np.asarray(t, dtype=np.float64) for t in (Q, R, Qf))
@@ -558,7 +564,9 @@ def differentialDynamicProgramming(dynFun, f_torch, Q, R, Qf, x0, uGuess, maxIte
         cost = conditionQuadraticCost(quadratic_cost_from_trajectory(Q, R, traj))
         Vf = conditionValueFunction(terminal_value_function(Qf, traj.xTraj[-1]))
         policy = backwardPass_ddp(dyn, cost, Vf)
-        traj_new, J_new = forwardPass2(x0, dynFun, runningCost, terminalCost, policy, traj)
+        traj_new, J_new, idx, Js = forwardPass2(x0, dynFun, runningCost, terminalCost, policy, traj, return_index=True)
+        if trace is not None:
+            trace.append((J_new, idx, Js))
         converged = bool(abs(J - J_new) <= tol)
         traj, J = traj_new, J_new
         it += 1

@@ -339,6 +339,67 @@ def test_iterativeLqr_baseline_config4_full_size(mods):
     assert np.array_equal(ts.uTraj, traj.uTraj[sub], equal_nan=True) and np.array_equal(Ls, L[sub], equal_nan=True)
 
 
+def _agreement(J_gpu, a_gpu, trace, rtol=1e-9):
+    """Leading iterations in which the kernel's cost after the acceptance step and its winning step-size index agree with the
+    oracle loop's (cost to `rtol`, NaN == NaN; index exactly)."""
+    k = 0
+    for (Jo, idx, _), Jg, ag in zip(trace, J_gpu, a_gpu):
+        same_J = (np.isnan(Jo) and np.isnan(Jg)) or (Jo == Jg) or (np.isfinite(Jo) and np.isfinite(Jg) and
+                                                                   abs(Jo - Jg) <= rtol * abs(Jo))
+        if not (same_J and int(ag) == idx):
+            break
+        k += 1
+    return k
+
+
+def test_iterativeLqr_non_converging_starts_follow_the_oracle_loop(mods):
+    """The ~9 % of BASELINE configs[3]'s 8192 starts that never converge (the reference has no regularisation and NaN wins
+    forwardPass2's argmin, ilqrUtils.py:140-150, 301-324): one start whose cost ends non-finite and one that runs to maxIter with a
+    finite cost are solved by `oracle.iterativeLqr` too.  Same `converged` (False), same finiteness of the final J, and -- through
+    zm_ilqr_solve_trace_f64's per-iteration record -- the same cost (1e-9) and the same winning step-size index iteration by
+    iteration for as long as the two chaotic iterations stay together (>= 10 required; the count is printed).  A start that went
+    NaN on the GPU only, or oscillated on the GPU only, would be a divergence of the HIP path: this is the test that sees it."""
+    import warnings
+    ilqr, models, pt, _ = mods
+    batch, N = 8192, 100
+    Q, R, Qf = np.eye(12), np.eye(4), 10 * np.eye(12)
+    cost = models.QuadraticCost(Q, R, Qf)
+    model = models.QuadcopterEuler(0.1)
+    rng = np.random.default_rng(2)
+    x0 = np.zeros((batch, 12))
+    x0[:, 9:12] = rng.uniform(-10, 10, (batch, 3))
+    ug = np.tile(models.QuadcopterEuler.uTrim, (batch, N, 1))
+    ilqr._TRACE = []
+    try:
+        traj, L, J, conv = ilqr.iterativeLqr(model, cost, cost, x0, ug)
+        rec = dict(ilqr._TRACE)
+    finally:
+        ilqr._TRACE = None
+    Jtr, atr = rec["J_trace"], rec["alpha_trace"]
+    assert Jtr.shape == (rec["iterations"], batch) and atr.shape == Jtr.shape
+    assert np.array_equal(Jtr[-1], J, equal_nan=True)                  # the record's last row is the returned cost
+    nonfinite = np.flatnonzero(~np.isfinite(J))
+    capped = np.flatnonzero(np.isfinite(J) & ~conv)
+    assert nonfinite.size > 0 and capped.size > 0, "the workload is expected to hold both kinds of non-converging starts"
+    assert not conv[nonfinite].any()
+    step = zo.quad_euler_step(0.1)
+    report = {}
+    for kind, i in (("J non-finite", int(nonfinite[0])), ("maxIter, J finite", int(capped[0]))):
+        tr = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                            # overflow / invalid: the reference's NaN path, on purpose
+            rt, rL, rJ, rc, its = zo.iterativeLqr(step, Q, R, Qf, x0[i], ug[i], return_iters=True, trace=tr)
+        agree = _agreement(Jtr[:, i], atr[:, i], tr)
+        report[kind] = (i, agree, its, float(J[i]), float(rJ))
+        assert rc is False and not conv[i], (kind, i)
+        assert its == N                                                # the oracle loop also runs to maxIter
+        assert np.isfinite(rJ) == np.isfinite(J[i]), (kind, i, rJ, J[i])
+        assert agree >= 10, (kind, i, agree)
+        if np.isfinite(rJ) and agree == its:                           # together to the end: the answers must then be the same
+            assert J[i] == pytest.approx(rJ, rel=1e-7) and _rel(traj.uTraj[i], rt.uTraj) <= 1e-5
+    print("iLQR non-converging starts vs oracle loop (index, iterations in agreement, oracle iterations, J kernel, J oracle):", report)
+
+
 def test_expansions_over_an_id_list_match_the_full_calls(mods):
     """zm_linearize_dynamics_list_f64 / zm_quadratize_cost_list_f64 / zm_quadratic_dynamics_list_f64: the listed trajectories get
     bit for bit what the plain entry points write, every other trajectory is left untouched, listed-but-inactive ones are skipped,

@@ -103,6 +103,8 @@ SYMBOLS = {
     #  iterations (host), batch, T, stream)
     "zm_ilqr_solve_f64": (ctypes.c_int, [_c_dp] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, _c_dp, ctypes.c_int64] +
                           [_c_dp] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "zm_ilqr_solve_trace_f64": (ctypes.c_int, [_c_dp] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, _c_dp, ctypes.c_int64] +
+                                [_c_dp] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, _c_dp, _c_dp]),
     "zm_model_nonlinear_mask": (ctypes.c_int, [_c_dp, _c_dp]),
     "zm_psd_project_f64": (ctypes.c_int, [_c_dp, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
     "zm_condition_cost_f64": (ctypes.c_int, [_c_dp] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double,

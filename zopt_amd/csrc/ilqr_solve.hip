@@ -148,10 +148,10 @@ extern "C" int64_t zm_ilqr_solve_workspace_f64(const zm_model_t* model, int64_t 
     return zm::carve(batch, T, model->n, model->m, ddp, (mask >> model->n) != 0, npairs).total;
 }
 
-extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0, const double* uGuess,
-                                 int ddp, int max_iter, double tol, int sync_every, double* workspace, int64_t workspace_doubles,
-                                 int32_t* iwork, double* xTraj, double* uTraj, double* L, double* J, int32_t* converged,
-                                 int32_t* iterations, int64_t batch, int T, void* stream) {
+static int ilqr_solve_impl(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0, const double* uGuess,
+                           int ddp, int max_iter, double tol, int sync_every, double* workspace, int64_t workspace_doubles,
+                           int32_t* iwork, double* xTraj, double* uTraj, double* L, double* J, int32_t* converged,
+                           int32_t* iterations, int64_t batch, int T, void* stream, double* J_trace, int32_t* alpha_trace) {
     if (batch == 0) return ZM_OK;
     if (!model || !cost || !x0 || !uGuess || !workspace || !iwork || !xTraj || !uTraj || !L || !J || !converged)
         return zm::set_error(ZM_EINVAL, "zm_ilqr_solve_f64: null pointer");
@@ -330,6 +330,11 @@ extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* c
                                     n, m, st);
         }
         if (rc) return rc;
+        // diagnostics (zm_ilqr_solve_trace_f64): row `it` <- every trajectory's cost after this iteration's acceptance step and the
+        // line search's winning step-size index (meaningful for the trajectories that were active in this iteration)
+        if (J_trace) ZM_HIP_CHECK(hipMemcpyAsync(J_trace + (long)it * batch, J, sizeof(double) * batch, hipMemcpyDeviceToDevice, st));
+        if (alpha_trace)
+            ZM_HIP_CHECK(hipMemcpyAsync(alpha_trace + (long)it * batch, widx, sizeof(int32_t) * batch, hipMemcpyDeviceToDevice, st));
     }
     if (swap_on) {
         rc = zm::ilqr_collect(where, xTraj, ws + w.xT2, uTraj, ws + w.uT2, batch, T, n, m, st);
@@ -337,4 +342,21 @@ extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* c
     }
     if (iterations) *iterations = it;
     return ZM_OK;
+}
+
+extern "C" int zm_ilqr_solve_f64(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0, const double* uGuess,
+                                 int ddp, int max_iter, double tol, int sync_every, double* workspace, int64_t workspace_doubles,
+                                 int32_t* iwork, double* xTraj, double* uTraj, double* L, double* J, int32_t* converged,
+                                 int32_t* iterations, int64_t batch, int T, void* stream) {
+    return ilqr_solve_impl(model, cost, x0, uGuess, ddp, max_iter, tol, sync_every, workspace, workspace_doubles, iwork, xTraj, uTraj, L,
+                           J, converged, iterations, batch, T, stream, nullptr, nullptr);
+}
+
+extern "C" int zm_ilqr_solve_trace_f64(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0, const double* uGuess,
+                                       int ddp, int max_iter, double tol, int sync_every, double* workspace,
+                                       int64_t workspace_doubles, int32_t* iwork, double* xTraj, double* uTraj, double* L, double* J,
+                                       int32_t* converged, int32_t* iterations, int64_t batch, int T, void* stream, double* J_trace,
+                                       int32_t* alpha_trace) {
+    return ilqr_solve_impl(model, cost, x0, uGuess, ddp, max_iter, tol, sync_every, workspace, workspace_doubles, iwork, xTraj, uTraj, L,
+                           J, converged, iterations, batch, T, stream, J_trace, alpha_trace);
 }

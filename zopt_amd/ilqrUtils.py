@@ -137,7 +137,8 @@ def riccatiStep_ddp(dynamics, cost, value):
 
 
 LINESEARCH_ALPHAS = 0.5 ** np.arange(16)   # reference ilqrUtils.py:145
-_TRACE = None   # diagnostics: a list that receives (iteration, active trajectories) at every host synchronisation
+_TRACE = None   # diagnostics: a list; while it is one, the fused drivers run zm_ilqr_solve_trace_f64 and append ("iterations", its),
+#                 ("J_trace", (its, batch) costs after every iteration's acceptance), ("alpha_trace", (its, batch) winning step-size indices)
 
 
 def _rollout(x0, dynFun, policy, trajPrev, alphas, costFun):
@@ -450,12 +451,20 @@ def _ilqr_or_ddp(dynamics, runningCost, terminalCost, x0, uGuess, maxIter, tol, 
         ws = torch.empty(nws, dtype=dt, device=dev)
         iwork = torch.empty(2 * B + 2, dtype=torch.int32, device=dev)
         its = ctypes.c_int32(0)
-        rc = lib.zm_ilqr_solve_f64(pmd, pcs, dx0.data_ptr(), dug.data_ptr(), 1 if ddp else 0, int(maxIter), float(tol), SYNC,
-                                   ws.data_ptr(), nws, iwork.data_ptr(), xT.data_ptr(), uT.data_ptr(), L.data_ptr(), J.data_ptr(),
-                                   converged.data_ptr(), ctypes.addressof(its), B, N, st)
+        common = (pmd, pcs, dx0.data_ptr(), dug.data_ptr(), 1 if ddp else 0, int(maxIter), float(tol), SYNC,
+                  ws.data_ptr(), nws, iwork.data_ptr(), xT.data_ptr(), uT.data_ptr(), L.data_ptr(), J.data_ptr(),
+                  converged.data_ptr(), ctypes.addressof(its), B, N, st)
+        if _TRACE is None:
+            rc = lib.zm_ilqr_solve_f64(*common)
+        else:
+            Jtr = torch.full((max(int(maxIter), 1), B), float("nan"), dtype=dt, device=dev)
+            atr = torch.full((max(int(maxIter), 1), B), -1, dtype=torch.int32, device=dev)
+            rc = lib.zm_ilqr_solve_trace_f64(*common, Jtr.data_ptr(), atr.data_ptr())
         _lib.check(rc, "differentialDynamicProgramming" if ddp else "iterativeLqr")
         if _TRACE is not None:
             _TRACE.append(("iterations", int(its.value)))
+            _TRACE.append(("J_trace", Jtr[: int(its.value)].cpu().numpy()))
+            _TRACE.append(("alpha_trace", atr[: int(its.value)].cpu().numpy()))
     tmpl = uGuess
     fp32_in = (arr.is_torch(tmpl) and tmpl.dtype == torch.float32) or \
         (not arr.is_torch(tmpl) and np.asarray(tmpl).dtype == np.float32)
