@@ -36,6 +36,11 @@ int zm_version(void);
 /* Thread-local description of the last error returned on this thread ("" if none). */
 const char* zm_last_error(void);
 
+/* Releases the few host-side resources the library keeps between calls (one pinned int32 + one event per device and concurrent
+ * zm_ilqr_solve_f64 caller, used for the drivers' host round trips); returns how many were released.  Call it before unloading the
+ * library or destroying the HIP context; calling it at any other time is harmless (the next solve re-creates what it needs). */
+int zm_shutdown(void);
+
 /* 1 if (n, m) is covered by the compiled LQR sweep kernels for the given element size, else 0.
  *   8 = fp64: tile-16 MFMA kernels for n <= 12, m <= 4 (the LDS-DMA fast path at n in {8, 12}, m = 4: ~1.5e9 steps/s at (12, 4));
  *             register-tile fp64 MFMA kernel for n <= 48, m <= 16 (47 M steps/s at (48, 16)); for 48 < n <= 64 an LDS-resident
@@ -71,7 +76,9 @@ int zm_lqr_backward_affine_f64(const double* A, const double* B, const double* d
  * Replaces: zopt/lqrUtils.py:176-204 discreteInfiniteHorizonLqr (SciPy solve_discrete_are + one solve).
  * in : A (batch,n,n)  B (batch,n,m)  Q (batch,n,n)  R (batch,m,m)   [device]; n <= 12, m <= 4
  *      tol: stop when max|V' - V| <= tol * max|V'| (or at the rounding floor); max_iter: iteration cap
- * out: L (batch,m,n) with u = -L x;  P (batch,n,n) or NULL: the value matrix;  iters (batch) or NULL
+ * out: L (batch,m,n) with u = -L x;  P (batch,n,n) or NULL: the value matrix;
+ *      iters (batch) or NULL: +k = converged after k iterations (also when k == max_iter), -k = the cap ended the loop after k
+ *      iterations without the stopping test being met (the gain is then not a stationary one)
  */
 int zm_dare_f64(const double* A, const double* B, const double* Q, const double* R, double* L, double* P, int32_t* iters,
                 int64_t batch, int n, int m, double tol, int max_iter, void* stream);
@@ -384,9 +391,12 @@ int zm_ddp_backward_pairs_list_f64(const zm_model_t* model, const double* f_x, c
  * :360-397 (differentialDynamicProgramming, ddp != 0) for a registered model and quadratic cost -- initial rollout of
  * (uGuess, L = 0), then per iteration the expansions along the trajectory, the PD-conditioned Hessians, the backward pass, the
  * 16-way line search and `converged = |J - J_new| <= tol`, each over the compacted list of the trajectories that have not
- * converged yet (rebuilt on the device every `sync_every` >= 1 iterations; results do not depend on it).  The host side of the
- * loop runs inside this call; it synchronises the stream every `sync_every` iterations and returns with work possibly still
- * queued on `stream`.
+ * converged yet (rebuilt on the device every `sync_every` >= 1 iterations; results do not depend on it).
+ * HOST-SYNCHRONOUS, unlike the other `*_f64` entry points: the host side of the loop runs inside this call and BLOCKS the calling
+ * thread on an event every `sync_every` iterations (it must learn how many trajectories are left to size the next launches), so the
+ * call returns only when the loop has ended -- after `max_iter` iterations or once every trajectory has converged -- with the last
+ * iteration's kernels and the final collect possibly still queued on `stream` (synchronise it before reading the outputs).  Work
+ * queued on OTHER streams overlaps as usual.
  * in : x0 (batch,n)  uGuess (batch,T,m)  [device]
  *      workspace: at least zm_ilqr_solve_workspace_f64(model, batch, T, ddp) doubles, 16-B aligned [device]
  *      iwork: 2 * batch + 2 int32 [device]

@@ -15,6 +15,6 @@ def pytest_sessionstart(session):
     git-ignored build products) compile them once -- the same step as __graft_entry__.build(); hipcc cross-compiles without a GPU.
     The product itself never builds on demand: zopt_amd._lib.lib() fails loudly when the library is missing."""
     from zopt_amd import _lib
-    if not os.path.exists(_lib.LIB_PATH) and not os.environ.get("ZOPT_AMD_LIB"):
+    if (not os.path.exists(_lib.LIB_PATH) or not os.path.exists(_lib.LAB_LIB_PATH)) and not os.environ.get("ZOPT_AMD_LIB"):
         import __graft_entry__
         __graft_entry__.build()

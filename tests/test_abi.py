@@ -124,3 +124,36 @@ def test_no_gpu_means_loud_failure():
     I = np.repeat(np.eye(2)[None], 2, axis=0)
     with pytest.raises(_lib.ZoptAmdError):
         lqrUtils.discreteFiniteHorizonLqr(I, I, I, I, 2)
+
+
+def test_lab_switches_exist_only_in_the_lab_build():
+    """The product library reads four environment variables, each selecting a fallback kernel; the kernel lab's A/B switches are
+    compiled in only with -DZM_LAB (zm_common.h: lab_env) -- their names must not even occur in the product binary."""
+    from zopt_amd import _lib
+    prod = open(_lib.LIB_PATH, "rb").read()
+    lab = open(_lib.LAB_LIB_PATH, "rb").read()
+    for name in (b"ZOPT_AMD_LQR_PATH", b"ZOPT_AMD_ILQR_PATH", b"ZOPT_AMD_ROLLOUT_PATH", b"ZOPT_AMD_MPC_PATH"):
+        assert name in prod and name in lab
+    for name in (b"ZOPT_AMD_ILQR_TAIL", b"ZOPT_AMD_JAC", b"ZOPT_AMD_HES", b"ZOPT_AMD_ILQR_SWAP", b"ZOPT_AMD_EXPAND", b"ZOPT_AMD_SWEEP_WG4",
+                 b"ZOPT_AMD_LQR_G4", b"ZOPT_AMD_LQR_D", b"ZOPT_AMD_LQR_F32", b"ZOPT_AMD_ROLLOUT_QUAD", b"ZOPT_AMD_QUAD_ALL_MAX",
+                 b"ZOPT_AMD_TILED_GENERIC"):
+        assert name not in prod, name
+        assert name in lab, name
+    import re
+    assert sorted(set(re.findall(rb"ZOPT_AMD_[A-Z0-9_]+", prod))) == [b"ZOPT_AMD_ILQR_PATH", b"ZOPT_AMD_LQR_PATH", b"ZOPT_AMD_MPC_PATH",
+                                                                       b"ZOPT_AMD_ROLLOUT_PATH"]
+
+
+def test_ilqr_workspace_omits_the_all_store_scratch_where_the_line_search_cannot_use_it():
+    """zm_ilqr_solve_workspace_f64 (host-only sizing): the all-store scratch of the tail's line search -- 16 step sizes x 16 doubles
+    per step for up to 2048 trajectories, 423 MB at T = 100 -- is reserved only for models whose line search can run in that form
+    (still-air quadcopter); a windy quadcopter's workspace is smaller by exactly that block."""
+    import ctypes
+    from zopt_amd import _lib, models
+    lib = _lib.lib()
+    still, windy = models.QuadcopterEuler(0.1).c_struct(), models.QuadcopterEuler(0.1, wind_ned=(1.0, 0.0, 0.0)).c_struct()
+    for batch, T in ((4096, 100), (100, 7)):
+        a = lib.zm_ilqr_solve_workspace_f64(ctypes.addressof(still), batch, T, 0)
+        b = lib.zm_ilqr_solve_workspace_f64(ctypes.addressof(windy), batch, T, 0)
+        assert a > 0 and b > 0
+        assert a - b == min(batch, 2048) * (T + 1) * 256

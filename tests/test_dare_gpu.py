@@ -60,7 +60,7 @@ def test_torch_batch_axes_and_iteration_cap(lqr):
     Lr, _ = zo.discreteInfiniteHorizonLqr(A[4], B[4], Q[4], R[4])
     assert np.max(np.abs(L[1, 1].cpu().numpy() - Lr)) <= 1e-10 * np.max(np.abs(Lr))
     Lc, Vc, its = lqr.discreteInfiniteHorizonLqr(A, B, Q, R, maxIter=5, return_value=True)    # capped: 5 Riccati steps
-    assert np.all(its == 5)
+    assert np.all(its == -5)                            # explicit status: the cap ended the loop, after 5 iterations
     Af, Bf, Qf, Rf = problems.tile_over_horizon(A, B, Q, R, 6)
     Lf = lqr.discreteFiniteHorizonLqr(Af, Bf, Qf, Rf, 6)
     assert np.max(np.abs(Lc - Lf[:, 0])) <= 1e-12 * np.max(np.abs(Lc))      # = L_0 of the 6-step horizon from V = Q
@@ -70,3 +70,13 @@ def test_torch_batch_axes_and_iteration_cap(lqr):
         lqr.discreteInfiniteHorizonLqr(np.diag([2.0, 0.5]), np.array([[0.0], [1.0]]), np.eye(2), np.eye(1), maxIter=2000)
     with pytest.raises(ValueError):
         lqr.discreteInfiniteHorizonLqr(np.eye(13), np.ones((13, 2)), np.eye(13), np.eye(2))
+    # convergence EXACTLY on the last allowed iteration is convergence (the kernel reports it, the count alone cannot tell):
+    # a design that needs k iterations is accepted with maxIter = k and refused with maxIter = k - 4 (the test runs every 4th)
+    L1, _, k = lqr.discreteInfiniteHorizonLqr(A[:1], B[:1], Q[:1], R[:1], return_value=True)
+    k = int(k[0])
+    assert k > 8 and k % 4 == 0
+    L2, _, k2 = lqr.discreteInfiniteHorizonLqr(A[:1], B[:1], Q[:1], R[:1], maxIter=k, return_value=True)
+    assert int(k2[0]) == k and np.array_equal(L1, L2)
+    assert np.array_equal(lqr.discreteInfiniteHorizonLqr(A[:1], B[:1], Q[:1], R[:1], maxIter=k), L1)      # no LinAlgError
+    with pytest.raises(np.linalg.LinAlgError):
+        lqr.discreteInfiniteHorizonLqr(A[:1], B[:1], Q[:1], R[:1], maxIter=k - 4)

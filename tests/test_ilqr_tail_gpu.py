@@ -11,6 +11,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the A/B switches exist only in the -DZM_LAB build of the library (zm_common.h: lab_env); the child processes load that one
+LAB_ENVIRON = dict(os.environ, ZOPT_AMD_LIB=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zopt_amd", "csrc",
+                                                          "libzopt_amd_lab.so"))
+
 
 CHILD = r"""
 import sys, numpy as np
@@ -45,7 +49,7 @@ def test_solve_is_bit_identical_for_every_tail_threshold(solver, tmp_path):
     for thr, quad, jac in cases:
         out = tmp_path / f"{solver}_{thr}_{quad}_{jac}.npz"
         p = subprocess.run([sys.executable, "-c", CHILD, str(out), solver],
-                           env=dict(os.environ, ZOPT_AMD_ILQR_TAIL=thr, ZOPT_AMD_ROLLOUT_QUAD=quad, ZOPT_AMD_JAC=jac.split("-")[0],
+                           env=dict(LAB_ENVIRON, ZOPT_AMD_ILQR_TAIL=thr, ZOPT_AMD_ROLLOUT_QUAD=quad, ZOPT_AMD_JAC=jac.split("-")[0],
                                     ZOPT_AMD_EXPAND="group" if jac.endswith("group") else "points",
                                     ZOPT_AMD_ILQR_SWAP="0" if jac.endswith("copy") else "1",
                                     ZOPT_AMD_HES="dense" if quad == "0" else "sparse"), capture_output=True,
@@ -68,7 +72,7 @@ def test_short_and_odd_horizons_agree_across_line_search_forms(N, tmp_path):
     for thr, quad in cases:
         out = tmp_path / f"h{N}_{thr}_{quad}.npz"
         p = subprocess.run([sys.executable, "-c", CHILD, str(out), "ilqr", str(N)],
-                           env=dict(os.environ, ZOPT_AMD_ILQR_TAIL=thr, ZOPT_AMD_ROLLOUT_QUAD=quad), capture_output=True, text=True,
+                           env=dict(LAB_ENVIRON, ZOPT_AMD_ILQR_TAIL=thr, ZOPT_AMD_ROLLOUT_QUAD=quad), capture_output=True, text=True,
                            timeout=600, cwd=ROOT)
         assert p.returncode == 0 and "CHILD-OK" in p.stdout, (p.stdout[-300:], p.stderr[-1500:])
         res[(thr, quad)] = dict(np.load(out))
@@ -85,7 +89,7 @@ def test_horizon_of_several_chunks_agrees_across_expansion_forms(wind, tmp_path)
     res = {}
     for form in ("points", "group"):
         out = tmp_path / f"long_{wind}_{form}.npz"
-        p = subprocess.run([sys.executable, "-c", CHILD, str(out), "ddp", "131", wind], env=dict(os.environ, ZOPT_AMD_EXPAND=form),
+        p = subprocess.run([sys.executable, "-c", CHILD, str(out), "ddp", "131", wind], env=dict(LAB_ENVIRON, ZOPT_AMD_EXPAND=form),
                            capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert p.returncode == 0 and "CHILD-OK" in p.stdout, (p.stdout[-300:], p.stderr[-1500:])
         res[form] = dict(np.load(out))
@@ -104,7 +108,7 @@ def test_windy_model_packed_and_full_operands_agree_and_match_the_oracle(solver,
     for jac, hes in (("packed", "sparse"), ("full", "dense")):
         out = tmp_path / f"w_{solver}_{jac}.npz"
         p = subprocess.run([sys.executable, "-c", CHILD, str(out), solver, "12", "wind"],
-                           env=dict(os.environ, ZOPT_AMD_JAC=jac, ZOPT_AMD_HES=hes), capture_output=True, text=True, timeout=900, cwd=ROOT)
+                           env=dict(LAB_ENVIRON, ZOPT_AMD_JAC=jac, ZOPT_AMD_HES=hes), capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert p.returncode == 0 and "CHILD-OK" in p.stdout, (p.stdout[-300:], p.stderr[-1500:])
         res[jac] = dict(np.load(out))
     for k in ("x", "u", "L", "J", "c"):

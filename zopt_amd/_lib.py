@@ -103,6 +103,7 @@ SYMBOLS = {
     #  iterations (host), batch, T, stream)
     "zm_ilqr_solve_f64": (ctypes.c_int, [_c_dp] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, _c_dp, ctypes.c_int64] +
                           [_c_dp] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "zm_shutdown": (ctypes.c_int, []),
     "zm_ilqr_solve_trace_f64": (ctypes.c_int, [_c_dp] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, _c_dp, ctypes.c_int64] +
                                 [_c_dp] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, _c_dp, _c_dp]),
     "zm_model_nonlinear_mask": (ctypes.c_int, [_c_dp, _c_dp]),
@@ -119,14 +120,19 @@ class ZoptAmdError(RuntimeError):
 _lib = None
 
 
-def build(verbose: bool = False) -> str:
-    """Compile the HIP sources for gfx950 in-tree (``make -C zopt_amd/csrc``)."""
-    out = subprocess.run(["make", "-C", CSRC, f"-j{max(1, min(8, os.cpu_count() or 1))}"], capture_output=True, text=True)
-    if verbose or out.returncode != 0:
-        print(out.stdout)
-        print(out.stderr)
-    if out.returncode != 0:
-        raise ZoptAmdError("building libzopt_amd.so failed (hipcc --offload-arch=gfx950)")
+LAB_LIB_PATH = os.path.join(CSRC, "libzopt_amd_lab.so")   # -DZM_LAB build: the A/B switches of the kernel lab compiled in (tests, tools)
+
+
+def build(verbose: bool = False, lab: bool = True) -> str:
+    """Compile the HIP sources for gfx950 in-tree (``make -C zopt_amd/csrc``): the product library and, with `lab`, the
+    -DZM_LAB build of the same sources that the A/B tests load through ZOPT_AMD_LIB."""
+    for target in ([], ["lab"]) if lab else ([],):
+        out = subprocess.run(["make", "-C", CSRC, f"-j{max(1, min(8, os.cpu_count() or 1))}"] + target, capture_output=True, text=True)
+        if verbose or out.returncode != 0:
+            print(out.stdout)
+            print(out.stderr)
+        if out.returncode != 0:
+            raise ZoptAmdError("building libzopt_amd.so failed (hipcc --offload-arch=gfx950)")
     return LIB_PATH
 
 
@@ -153,6 +159,8 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = handle
+        import atexit
+        atexit.register(handle.zm_shutdown)      # pinned words / events of the drivers, while the HIP runtime is still up
     return _lib
 
 

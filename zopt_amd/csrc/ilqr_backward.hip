@@ -849,7 +849,7 @@ static int ilqr_backward_dma_dispatch(const double* f_x, const double* f_u, cons
                                       double* l, double* L, int64_t batch, int T, int n, int m, hipStream_t st,
                                       TrajList tl = TrajList{nullptr, 0}) {
     static const bool off = [] {
-        const char* e = getenv("ZOPT_AMD_ILQR_PATH");
+        const char* e = zm::fallback_env("ZOPT_AMD_ILQR_PATH");
         return e && e[0] == 'r';   // "reg": force the register-prefetch kernel
     }();
     if (off || m != 4 || (n != 8 && n != 12)) return ZM_EUNSUPPORTED;
@@ -884,7 +884,7 @@ static int ddp_backward_dma_dispatch(const double* f_x, const double* f_u, const
                                      const double* vf_xx, long svx, const int* act, int sh, double* l, double* L, int64_t batch, int T,
                                      int n, int m, hipStream_t st, TrajList tl) {
     static const bool off = [] {
-        const char* e = getenv("ZOPT_AMD_ILQR_PATH");
+        const char* e = zm::fallback_env("ZOPT_AMD_ILQR_PATH");
         return e && e[0] == 'r';   // "reg": force the register kernel
     }();
     if (off || !sh || n != 12 || m != 4 || ptab.n != 28 || !Hpk) return ZM_EUNSUPPORTED;
@@ -914,7 +914,7 @@ int sweep_packed_jacobians(const double* Fp, int njp, const unsigned char* pos, 
     const long nslot = tl.list ? tl.count : batch;
     // few trajectories left (at most one wave per SIMD): four-wave workgroups, one wave per SIMD of a CU
     static const long wg4_max = [] {   // ZOPT_AMD_SWEEP_WG4=<n>: four-wave workgroups up to n listed trajectories (A/B)
-        const char* e = getenv("ZOPT_AMD_SWEEP_WG4");
+        const char* e = zm::lab_env("ZOPT_AMD_SWEEP_WG4");
         return e ? atol(e) : 1024L;
     }();
     const bool quad_wg = tl.list && nslot <= wg4_max;

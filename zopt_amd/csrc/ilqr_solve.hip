@@ -12,6 +12,8 @@
 #include <utility>
 #include <cstdint>
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 
 #include "models.h"
 #include "quad_derivs_gen.h"
@@ -74,7 +76,7 @@ struct IlqrWs {   // carve of the caller's workspace (doubles)
 constexpr long ILQR_TAIL_DEFAULT = 2048;
 static long ilqr_tail_slots(long batch) {
     static const long thr = [] {
-        const char* e = getenv("ZOPT_AMD_ILQR_TAIL");
+        const char* e = zm::lab_env("ZOPT_AMD_ILQR_TAIL");
         return e ? atol(e) : ILQR_TAIL_DEFAULT;
     }();
     return thr < 0 ? 0 : (thr < batch ? thr : batch);
@@ -94,6 +96,7 @@ int sweep_packed_jacobians(const double* Fp, int njp, const unsigned char* pos, 
 int quad_hessian_sparse_list(const zm_model_t* model, const double* xTraj, const double* uTraj, const int32_t* list, int64_t count,
                              const int32_t* active, double* Hs, int64_t batch, int T, void* stream);
 bool rollout_all_store_supported(const zm_model_t* model, const zm_quadcost_t* cost, int T);
+bool rollout_all_store_model_ok(const zm_model_t* model);
 int rollout_linesearch_all_store(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0, const double* l, const double* L,
                                  const double* xPrev, const double* uPrev, const double* alphas, const int32_t* list, int64_t count,
                                  const int32_t* active, double* scratch, double* J, int32_t* alpha_idx, int64_t batch, int T,
@@ -104,7 +107,8 @@ int ilqr_accept(const int32_t* list, int64_t count, double* J, const double* Jn,
 int ilqr_collect(const int32_t* where, double* xTraj, const double* xAlt, double* uTraj, const double* uAlt, int64_t batch, int T, int n,
                  int m, void* stream);
 
-static IlqrWs carve(long b, long T, long n, long m, int ddp, int need_ux, int npairs) {
+static IlqrWs carve(const zm_model_t* model, long b, long T, int ddp, int need_ux, int npairs) {
+    const long n = model->n, m = model->m;
     IlqrWs w;
     long o = 0;
     auto take = [&](long cnt) {
@@ -132,10 +136,78 @@ static IlqrWs carve(long b, long T, long n, long m, int ddp, int need_ux, int np
     w.f_uu = (ddp && need_ux && npairs == 0) ? take(b * T * n * m * m) : 0;
     w.idx = take((b + 1) / 2);   // int32 winner index per trajectory
     w.where = take((b + 1) / 2); // int32 per trajectory: 0 = newest rows in the caller's xTraj / uTraj, 1 = in xT2 / uT2
-    w.tail_slots = ilqr_tail_slots(b);
-    w.scratch = take(w.tail_slots * (T + 1) * 256);   // all-store blocks (n = 12, m = 4 only): 16 step sizes x 16 doubles per step
+    // all-store blocks (16 step sizes x 16 doubles per step and slot: 423 MB at T = 100 for 2048 slots) only for the models whose line
+    // search can run in that form -- a windy quadcopter, another model or the generic rollout path never touch them
+    w.tail_slots = rollout_all_store_model_ok(model) ? ilqr_tail_slots(b) : 0;
+    w.scratch = take(w.tail_slots * (T + 1) * 256);
     w.total = o;
     return w;
+}
+
+// Pool of (pinned int32, event) pairs per device for the drivers' host round trips.
+struct HostSlot {
+    int dev;
+    int32_t* word;
+    hipEvent_t event;
+    bool busy;
+};
+static std::mutex g_slot_mutex;
+static std::vector<HostSlot> g_slots;
+
+class HostSlotLease {
+  public:
+    explicit HostSlotLease(int dev) : idx_(-1) {
+        std::lock_guard<std::mutex> lk(g_slot_mutex);
+        for (size_t i = 0; i < g_slots.size(); ++i)
+            if (g_slots[i].dev == dev && !g_slots[i].busy) {
+                g_slots[i].busy = true;
+                idx_ = (long)i;
+                word_ = g_slots[i].word;
+                event_ = g_slots[i].event;
+                return;
+            }
+        HostSlot s{dev, nullptr, nullptr, true};
+        if (hipHostMalloc((void**)&s.word, sizeof(int32_t), hipHostMallocDefault) != hipSuccess) return;
+        if (hipEventCreateWithFlags(&s.event, hipEventDisableTiming) != hipSuccess) {
+            (void)hipHostFree(s.word);
+            return;
+        }
+        g_slots.push_back(s);
+        idx_ = (long)g_slots.size() - 1;
+        word_ = s.word;
+        event_ = s.event;
+    }
+    ~HostSlotLease() {
+        if (idx_ < 0) return;
+        std::lock_guard<std::mutex> lk(g_slot_mutex);
+        if ((size_t)idx_ < g_slots.size() && g_slots[idx_].word == word_) g_slots[idx_].busy = false;
+    }
+    bool ok() const { return idx_ >= 0; }
+    int32_t* word() const { return word_; }
+    hipEvent_t event() const { return event_; }
+
+  private:
+    long idx_;
+    int32_t* word_ = nullptr;
+    hipEvent_t event_ = nullptr;
+};
+
+// zm_shutdown(): frees every pair that is not lent out; returns how many were released.
+int release_host_slots() {
+    std::lock_guard<std::mutex> lk(g_slot_mutex);
+    int freed = 0;
+    std::vector<HostSlot> keep;
+    for (auto& s : g_slots) {
+        if (s.busy) {
+            keep.push_back(s);
+            continue;
+        }
+        (void)hipEventDestroy(s.event);
+        (void)hipHostFree(s.word);
+        ++freed;
+    }
+    g_slots.swap(keep);
+    return freed;
 }
 
 }  // namespace zm
@@ -145,7 +217,7 @@ extern "C" int64_t zm_ilqr_solve_workspace_f64(const zm_model_t* model, int64_t 
     uint32_t mask = 0;
     int32_t npairs = 0;
     if (ddp && (zm_model_nonlinear_mask(model, &mask) != ZM_OK || zm_model_hessian_pairs(model, nullptr, &npairs) != ZM_OK)) return -1;
-    return zm::carve(batch, T, model->n, model->m, ddp, (mask >> model->n) != 0, npairs).total;
+    return zm::carve(model, batch, T, ddp, (mask >> model->n) != 0, npairs).total;
 }
 
 static int ilqr_solve_impl(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0, const double* uGuess,
@@ -166,7 +238,7 @@ static int ilqr_solve_impl(const zm_model_t* model, const zm_quadcost_t* cost, c
         if (rc) return rc;
     }
     const int need_ux = (mask >> n) != 0;   // a model affine in its controls has f_ux = f_uu = 0: neither written nor read
-    const zm::IlqrWs w = zm::carve(batch, T, n, m, ddp, need_ux, npairs);
+    const zm::IlqrWs w = zm::carve(model, batch, T, ddp, need_ux, npairs);
     if (workspace_doubles < w.total)
         return zm::set_error(ZM_EINVAL, "zm_ilqr_solve_f64: workspace of %lld doubles, %lld needed", (long long)workspace_doubles,
                              (long long)w.total);
@@ -205,8 +277,8 @@ static int ilqr_solve_impl(const zm_model_t* model, const zm_quadcost_t* cost, c
     // Packed Jacobians (quadcopter): the expansion writes and the ring sweeps read only the structurally nonzero entries of
     // [f_x | f_u] -- 448 B (480 with wind) per point instead of 1 536 B.  ZOPT_AMD_JAC=full or ZOPT_AMD_ILQR_PATH=reg: the full matrices.
     static const bool packed_off = [] {
-        const char* e = getenv("ZOPT_AMD_JAC");
-        const char* r = getenv("ZOPT_AMD_ILQR_PATH");
+        const char* e = zm::lab_env("ZOPT_AMD_JAC");
+        const char* r = zm::fallback_env("ZOPT_AMD_ILQR_PATH");
         return (e && e[0] == 'f') || (r && r[0] == 'r');
     }();
     const bool windy = model->wind_ned[0] != 0.0 || model->wind_ned[1] != 0.0 || model->wind_ned[2] != 0.0;
@@ -218,34 +290,29 @@ static int ilqr_solve_impl(const zm_model_t* model, const zm_quadcost_t* cost, c
     // ... and the DDP path's second derivatives SPARSE (69 / 85 structurally nonzero entries of the 28 x 12 per point; ZOPT_AMD_HES=dense:
     // the dense pair rows)
     static const bool sparse_off = [] {
-        const char* e = getenv("ZOPT_AMD_HES");
+        const char* e = zm::lab_env("ZOPT_AMD_HES");
         return e && e[0] == 'd';
     }();
     const bool sparse_h = packed && ddp && !sparse_off;
     const int nh = windy ? zm::QUAD_NH_WIND : zm::QUAD_NH_STILL, nhs = (nh + 1) & ~1;
     const unsigned short* hdense = windy ? zm::QUAD_HDENSE_WIND : zm::QUAD_HDENSE_STILL;
     int32_t* widx = (int32_t*)(ws + w.idx);
-    // pinned word + event for the active count: one pair per (host thread, device), created on first use and kept (a pinned allocation
-    // per solve costs ~1 ms; an event belongs to the device that was current when it was created)
-    constexpr int MAXDEV = 64;
-    static thread_local int32_t* words[MAXDEV] = {nullptr};
-    static thread_local hipEvent_t events[MAXDEV] = {nullptr};
+    // pinned word + event for the active count, borrowed from a per-device pool for the duration of this call (a pinned allocation
+    // per solve costs ~1 ms; an event belongs to the device that was current when it was created).  Concurrent solves on one device
+    // get distinct pairs; zm_shutdown() releases the pool.
     int dev = 0;
     ZM_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= MAXDEV) return zm::set_error(ZM_EUNSUPPORTED, "zm_ilqr_solve_f64: device index %d", dev);
-    if (!words[dev]) {
-        ZM_HIP_CHECK(hipHostMalloc((void**)&words[dev], sizeof(int32_t), hipHostMallocDefault));
-        ZM_HIP_CHECK(hipEventCreateWithFlags(&events[dev], hipEventDisableTiming));
-    }
-    int32_t* const hcount_pinned = words[dev];
-    const hipEvent_t count_ready = events[dev];
+    zm::HostSlotLease lease(dev);
+    if (!lease.ok()) return zm::set_error(ZM_EUNSUPPORTED, "zm_ilqr_solve_f64: cannot get a pinned word / event on device %d", dev);
+    int32_t* const hcount_pinned = lease.word();
+    const hipEvent_t count_ready = lease.event();
     // The trajectories alternate between two buffers: the two-pass line search reads the current rows (xPrev, uPrev) and writes the
     // winner's into the other buffer, which then IS the current one -- the acceptance step copies nothing (it was 212 MB per
     // full-batch iteration).  Every active trajectory is rewritten in every iteration, so the current buffer is the same for all of
     // them; a trajectory that retires stays where it was last written (`where`), and the rows left in the workspace buffer move to
     // the caller's arrays once, at the end.  (ZOPT_AMD_ILQR_SWAP=0: the acceptance step copies, as before; same results.)
     static const bool swap_on = [] {
-        const char* e = getenv("ZOPT_AMD_ILQR_SWAP");
+        const char* e = zm::lab_env("ZOPT_AMD_ILQR_SWAP");
         return !(e && e[0] == '0');
     }();
     int32_t* where = (int32_t*)(ws + w.where);
@@ -360,3 +427,5 @@ extern "C" int zm_ilqr_solve_trace_f64(const zm_model_t* model, const zm_quadcos
     return ilqr_solve_impl(model, cost, x0, uGuess, ddp, max_iter, tol, sync_every, workspace, workspace_doubles, iwork, xTraj, uTraj, L,
                            J, converged, iterations, batch, T, stream, J_trace, alpha_trace);
 }
+
+extern "C" int zm_shutdown(void) { return zm::release_host_slots(); }

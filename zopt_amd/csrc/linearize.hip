@@ -680,7 +680,7 @@ int expand_list(const zm_model_t* model, const zm_quadcost_t* cost, const double
     if (packed && (!quad || md.dt == 0.0)) return set_error(ZM_EUNSUPPORTED, "expand_list: packed Jacobians need the quadcopter with dt != 0");
     // ZOPT_AMD_EXPAND=group: the packed expansion with 16 lanes per point (A/B; same results)
     static const bool by_points = [] {
-        const char* e = getenv("ZOPT_AMD_EXPAND");
+        const char* e = zm::lab_env("ZOPT_AMD_EXPAND");
         return !(e && e[0] == 'g');
     }();
     if (packed && by_points) {
@@ -880,7 +880,7 @@ int quad_hessian_sparse_list(const zm_model_t* model, const double* xTraj, const
     const dim3 grid16((unsigned)((npts + PPB16 - 1) / PPB16)), block16(64 * LIN_WAVES);
     const bool windy = md.wind_ned[0] != 0.0 || md.wind_ned[1] != 0.0 || md.wind_ned[2] != 0.0;
     static const bool by_points = [] {   // ZOPT_AMD_EXPAND=group: 16 lanes per point (A/B; same results)
-        const char* e = getenv("ZOPT_AMD_EXPAND");
+        const char* e = zm::lab_env("ZOPT_AMD_EXPAND");
         return !(e && e[0] == 'g');
     }();
     if (by_points) {

@@ -248,6 +248,7 @@ __global__ __launch_bounds__(64, 4) void dare_t16_f64(const double* __restrict__
 
     double lv = 0.0, prev = 1e300;
     int it = 0, stall = 0;
+    bool conv = false;
     while (it < max_iter) {   // every quantity in the loop condition is wave-uniform
         double Vo[KS];
 #pragma unroll
@@ -263,9 +264,15 @@ __global__ __launch_bounds__(64, 4) void dare_t16_f64(const double* __restrict__
             }
             df = wave_max(df);
             sc = wave_max(sc);
-            if (!(df > tol * sc)) break;                           // converged (or NaN: stop)
+            if (!(df > tol * sc)) {                                // converged (or NaN: stop; the caller sees the non-finite gain)
+                conv = true;
+                break;
+            }
             stall = (df >= prev && df <= 1e-9 * sc) ? stall + 1 : 0;   // rounding floor reached
-            if (stall >= 3) break;
+            if (stall >= 3) {
+                conv = true;
+                break;
+            }
             prev = df;
         }
     }
@@ -282,7 +289,9 @@ __global__ __launch_bounds__(64, 4) void dare_t16_f64(const double* __restrict__
         for (int s = 0; s < KS; ++s)
             if (4 * s + g < n && cA) P[sys * (long)(n * n) + (4 * s + g) * n + c] = V[s];
     }
-    if (iters && lane == 0) iters[sys] = it;
+    // explicit status: +iterations when the test above was met (also when that happened exactly on the last allowed iteration),
+    // -iterations when the cap ended the loop first
+    if (iters && lane == 0) iters[sys] = conv ? it : -it;
 }
 
 // lqr_backward_dma.hip: LDS-DMA staged fast path (even n, m; 16-B aligned pointers); ZM_EUNSUPPORTED otherwise.
@@ -319,7 +328,7 @@ extern "C" int zm_lqr_backward_f64(const double* A, const double* B, const doubl
     if (n > 12 || m > 4) {
         // medium sizes: fp64 MFMA tile kernel (n <= 48); beyond, or with ZOPT_AMD_LQR_PATH=lds: the LDS coverage kernel
         static const bool force_lds = [] {
-            const char* e = getenv("ZOPT_AMD_LQR_PATH");
+            const char* e = zm::fallback_env("ZOPT_AMD_LQR_PATH");
             return e && e[0] == 'l';
         }();
         if (!force_lds) {
@@ -330,7 +339,7 @@ extern "C" int zm_lqr_backward_f64(const double* A, const double* B, const doubl
     }
     // ZOPT_AMD_LQR_PATH=reg forces the register-prefetch kernel (A/B measurements); default: LDS-DMA when eligible.
     static const bool force_reg = [] {
-        const char* e = getenv("ZOPT_AMD_LQR_PATH");
+        const char* e = zm::fallback_env("ZOPT_AMD_LQR_PATH");
         return e && e[0] == 'r';
     }();
     if (!force_reg) {

@@ -330,11 +330,11 @@ static int launch_dma(const double* A, const double* B, const double* Q, const d
     // default: the [Sux | Suu] rows by v_mfma_f64_4x4x4_4b blocks (+2.6 % at steady state); ZOPT_AMD_LQR_G4=0 selects the three
     // full-tile MFMAs instead (A/B measurements)
     static const bool g4 = [] {
-        const char* e = getenv("ZOPT_AMD_LQR_G4");
+        const char* e = zm::lab_env("ZOPT_AMD_LQR_G4");
         return !(e && e[0] == '0');
     }();
     static const int depth = [] {   // ring depth (steps in flight per wave): 3 unless ZOPT_AMD_LQR_D=2 (A/B measurements)
-        const char* e = getenv("ZOPT_AMD_LQR_D");
+        const char* e = zm::lab_env("ZOPT_AMD_LQR_D");
         return (e && e[0] == '2') ? 2 : 3;
     }();
     const dim3 grid((unsigned)batch), block(64);

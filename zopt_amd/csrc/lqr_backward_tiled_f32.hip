@@ -43,7 +43,7 @@ extern "C" int zm_lqr_backward_f32(const float* A, const float* B, const float* 
     {   // the small fast-path shapes: K1 (LDS-DMA ring, tile-16 fp64 MFMA) on fp32 arrays -- fp32 storage, fp64 arithmetic, half the
         // HBM bytes of the fp64 call and no conversion passes (lqr_backward_dma.hip).  ZOPT_AMD_LQR_F32=tile: the fp32 tile kernel.
         static const bool tile_only = [] {
-            const char* e = getenv("ZOPT_AMD_LQR_F32");
+            const char* e = zm::lab_env("ZOPT_AMD_LQR_F32");
             return e && e[0] == 't';
         }();
         if (!tile_only) {

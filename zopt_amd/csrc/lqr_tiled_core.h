@@ -585,7 +585,7 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled(const typename TR::S* _
 template <class TR, int NT>
 static int launch_tiled(const typename TR::S* A, const typename TR::S* B, const typename TR::S* Q, const typename TR::S* R,
                         typename TR::S* L, int64_t batch, int T, int n, int m, hipStream_t st) {
-    const bool exact = (n == 16 * NT) && (m == 16) && !getenv("ZOPT_AMD_TILED_GENERIC");
+    const bool exact = (n == 16 * NT) && (m == 16) && !zm::lab_env("ZOPT_AMD_TILED_GENERIC");
     if (exact)
         hipLaunchKernelGGL((lqr_backward_tiled<TR, NT, true>), dim3((unsigned)batch), dim3(64), 0, st, A, B, Q, R, L, (long)batch, T, n,
                            m);

@@ -502,7 +502,7 @@ extern "C" int zm_mpc_solve_relaxed_f64(const double* A, const double* B, const 
     // default: 16 lanes per instance with the iterates in LDS (mpc_wave.hip); ZOPT_AMD_MPC_PATH=lane forces the
     // lane-per-instance kernel below, which also takes the horizons that do not fit LDS (fixed penalty: level0 only)
     static const bool force_lane = [] {
-        const char* e = getenv("ZOPT_AMD_MPC_PATH");
+        const char* e = zm::fallback_env("ZOPT_AMD_MPC_PATH");
         return e && e[0] == 'l';
     }();
     if (!force_lane) {

@@ -175,7 +175,7 @@ static int rollout_impl(const zm_model_t* model, const zm_quadcost_t* cost, cons
     const bool hc = cost != nullptr;
     const int* act = (const int*)active;
     static const bool force_generic = [] {
-        const char* e = getenv("ZOPT_AMD_ROLLOUT_PATH");
+        const char* e = zm::fallback_env("ZOPT_AMD_ROLLOUT_PATH");
         return e && e[0] == 'g';
     }();
     const bool windy = md.wind_ned[0] != 0.0 || md.wind_ned[1] != 0.0 || md.wind_ned[2] != 0.0;   // fast path: still air only
@@ -222,15 +222,19 @@ extern "C" int zm_rollout_linesearch_list_f64(const zm_model_t* model, const zm_
 // of its slot ((T+1) * 256 doubles per slot, layout in rollout_fast.hip), alpha_idx[t] names the winner, nothing is written to
 // xTraj / uTraj.
 namespace zm {
-bool rollout_all_store_supported(const zm_model_t* model, const zm_quadcost_t* cost, int T) {
-    if (!model || !cost || T < 1) return false;
+// the part of the predicate below that is known when the workspace is sized (model kind, dimensions, wind, the fallback switch)
+bool rollout_all_store_model_ok(const zm_model_t* model) {
+    if (!model) return false;
     static const bool force_generic = [] {
-        const char* e = getenv("ZOPT_AMD_ROLLOUT_PATH");
+        const char* e = zm::fallback_env("ZOPT_AMD_ROLLOUT_PATH");
         return e && e[0] == 'g';
     }();
     const bool windy = model->wind_ned[0] != 0.0 || model->wind_ned[1] != 0.0 || model->wind_ned[2] != 0.0;
     const bool dims = model->kind == ZM_MODEL_QUADCOPTER || (model->kind == ZM_MODEL_LINEAR && model->n == 12 && model->m == 4);
     return !force_generic && !windy && dims;
+}
+bool rollout_all_store_supported(const zm_model_t* model, const zm_quadcost_t* cost, int T) {
+    return model && cost && T >= 1 && rollout_all_store_model_ok(model);
 }
 int rollout_linesearch_all_store(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0, const double* l, const double* L,
                                  const double* xPrev, const double* uPrev, const double* alphas, const int32_t* list, int64_t count,

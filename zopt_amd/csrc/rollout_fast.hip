@@ -373,7 +373,7 @@ int rollout_fast_dispatch(const zm_model_t& md, const double* Q, const double* R
                (long)batch, T, n_alpha, scratch, 0};
     // ZOPT_AMD_ROLLOUT_QUAD=0: everything in rollout_ls_fast_kernel (A/B; same results)
     static const bool quad_on = [] {
-        const char* e = getenv("ZOPT_AMD_ROLLOUT_QUAD");
+        const char* e = zm::lab_env("ZOPT_AMD_ROLLOUT_QUAD");
         return !(e && e[0] == '0');
     }();
     const bool quad = quad_on && md.kind == ZM_MODEL_QUADCOPTER && diagonal == 1 && n_alpha == 16 && J && idx;
@@ -383,7 +383,7 @@ int rollout_fast_dispatch(const zm_model_t& md, const double* Q, const double* R
     // run alone and the 4-trajectories-per-wave kernel is faster (measured: 1131 trajectories 145 against ~125 us; iLQR solve with the
     // switch-over at 640 / 800 / 1024 / 1280 trajectories: 42.65 / 42.4 / 42.3 / 43.0 ms).
     static const long quad_all_max = [] {   // ZOPT_AMD_QUAD_ALL_MAX: A/B of the switch-over (same results either side)
-        const char* e = getenv("ZOPT_AMD_QUAD_ALL_MAX");
+        const char* e = zm::lab_env("ZOPT_AMD_QUAD_ALL_MAX");
         return e ? atol(e) : 1024L;
     }();
     if (quad && scratch && count <= quad_all_max) return rollout_quad_all(qa, st);

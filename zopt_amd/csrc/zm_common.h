@@ -4,10 +4,27 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/zopt_amd.h"
 
 namespace zm {
+
+// Run-time switches.  A PRODUCT build reads exactly four environment variables, each selecting a FALLBACK kernel -- the one that
+// also serves the shapes / alignments its fast path refuses, so it is product code either way:
+//     ZOPT_AMD_LQR_PATH=lds|reg   ZOPT_AMD_ILQR_PATH=reg   ZOPT_AMD_ROLLOUT_PATH=generic   ZOPT_AMD_MPC_PATH=lane
+// Every other ZOPT_AMD_* variable is an A/B switch of the kernel lab (ring depth, packed / full operands, tail thresholds, ...):
+// it exists only in a -DZM_LAB build (`make lab` -> libzopt_amd_lab.so, loaded through ZOPT_AMD_LIB by the A/B tests and the lab
+// tools); in the product library lab_env() is the constant nullptr and the compiler removes the branch it guards.
+inline const char* fallback_env(const char* name) { return getenv(name); }
+inline const char* lab_env(const char* name) {
+#ifdef ZM_LAB
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // Thread-local last-error buffer behind zm_last_error().
 char* last_error_buf();

@@ -20,7 +20,25 @@ try:
     import torch
 except Exception:  # pragma: no cover
     torch = None
-from . import generic as _generic  # noqa: E402  (torch.func producers in front of the HIP sweeps for callable models)
+
+
+class _LazyGeneric:
+    """zopt_amd.generic (torch.func producers in front of the HIP sweeps for callable models) imports torch unconditionally; it is
+    loaded on first use so that `import zopt_amd.ilqrUtils` works on a host without torch, as the other modules do (calls raise)."""
+    _mod = None
+
+    @staticmethod
+    def is_callable_model(f):
+        return callable(f) and not hasattr(f, "c_struct")
+
+    def __getattr__(self, name):
+        if _LazyGeneric._mod is None:
+            from . import generic
+            _LazyGeneric._mod = generic
+        return getattr(_LazyGeneric._mod, name)
+
+
+_generic = _LazyGeneric()
 
 
 def _fields(t):

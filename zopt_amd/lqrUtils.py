@@ -111,7 +111,8 @@ def discreteInfiniteHorizonLqr(A, B, Q, R, tol=1e-14, maxIter=200000, return_val
 
     Returns
     -------
-        L : (..., m, n) optimal LQR gains `u = -L x`   (with `return_value=True`: (L, V, iterations))
+        L : (..., m, n) optimal LQR gains `u = -L x`   (with `return_value=True`: (L, V, iterations), iterations < 0 where the
+            cap ended the iteration before its stopping test was met)
     """
     shp = tuple(B.shape) if hasattr(B, "shape") else tuple(np.shape(B))
     if len(shp) < 2:
@@ -134,7 +135,9 @@ def discreteInfiniteHorizonLqr(A, B, Q, R, tol=1e-14, maxIter=200000, return_val
                                 its.data_ptr(), batch, n, m, float(tol), int(maxIter), ctypes.c_void_p(arr.stream_ptr(dA)))
     _lib.check(rc, "discreteInfiniteHorizonLqr")
     if batch and not return_value:      # with return_value=True the caller receives `iterations` and judges convergence itself
-        bad = (its.reshape(-1) >= int(maxIter)) | ~torch.isfinite(dL.reshape(batch, -1)).all(dim=1)
+        # the kernel reports convergence explicitly (iters < 0: the cap ended the loop); a design that meets the tolerance exactly on
+        # its last allowed iteration is converged
+        bad = (its.reshape(-1) <= 0) | ~torch.isfinite(dL.reshape(batch, -1)).all(dim=1)
         nbad = int(bad.sum())
         if nbad:   # SciPy's solve_discrete_are raises LinAlgError('Failed to find a finite solution.') there (lqrUtils.py:202)
             raise np.linalg.LinAlgError(f"discreteInfiniteHorizonLqr: no converged finite solution for {nbad} of {batch} designs "
