@@ -43,9 +43,9 @@ int zm_shutdown(void);
 
 /* 1 if (n, m) is covered by the compiled LQR sweep kernels for the given element size, else 0.
  *   8 = fp64: tile-16 MFMA kernels for n <= 12, m <= 4 (the LDS-DMA fast path at n in {8, 12}, m = 4: ~1.5e9 steps/s at (12, 4));
- *             register-tile fp64 MFMA kernel for n <= 48, m <= 16 (47 M steps/s at (48, 16)); for 48 < n <= 64 an LDS-resident
- *             COVERAGE kernel that is correct but untuned -- 1.4 M steps/s at n = 64, a 30x cliff against n = 48: use fp32
- *             (zm_lqr_backward_f32: 62 M steps/s at (64, 16)) when that precision is acceptable;
+ *             register-tile fp64 MFMA kernel for n <= 64, m <= 16: three tile rows with a prefetched operand set up to n = 48
+ *             (54 M steps/s at (48, 16)), four tile rows without it for 48 < n <= 64 (17 M steps/s at (64, 16); the LDS-resident
+ *             coverage kernel it replaced there ran 1.4 M and stays selectable with ZOPT_AMD_LQR_PATH=lds);
  *   4 = fp32: zm_lqr_backward_f32, n <= 64, m <= 16 (n in {8, 12}, m = 4 with 16-B aligned arrays: fp32 storage, fp64 arithmetic on
  *             the LDS-DMA ring kernel -- 1.8e9 steps/s at (12, 4); the other shapes up to 16: the fp32 MFMA tile kernel). */
 int zm_lqr_backward_supported(int n, int m, int elem_size);
@@ -132,6 +132,9 @@ int zm_lqr_backward_host_f64(const double* A, const double* B, const double* Q, 
  *      c_x (batch,T,n) c_u (batch,T,m) c_xx (batch,T,n,n) c_ux (batch,T,m,n) c_uu (batch,T,m,m)   QuadraticCostFunction (:84-98)
  *      vf_x (batch,n) vf_xx (batch,n,n)                             QuadraticValueFunction Vf (:58-69)
  * out: l (batch,T,m)  L (batch,T,m,n)                               AffinePolicy (:207-213), u = alpha*l + L dx + uPrev
+ * Shapes: n <= 12, m <= 4 on the tile-16 kernels (LDS-DMA ring at n in {8, 12}, m = 4); beyond, up to n <= 48, m <= 16, on the fp64
+ * MFMA tile sweep (sweep_tiled_f64.hip: V, [f_x | f_u] and every product as 16 x 16 register tiles, one wave per trajectory);
+ * ZM_EUNSUPPORTED above.  zm_lqr_backward_affine_f64 takes the same shapes.
  */
 int zm_ilqr_backward_f64(const double* f_x, const double* f_u, const double* c_x, const double* c_u,
                          const double* c_xx, const double* c_ux, const double* c_uu, const double* vf_x,

@@ -120,9 +120,11 @@ def test_unsupported_shapes_raise(lqr):
 
 
 @pytest.mark.parametrize("n,m,T,batch", [(64, 16, 6, 3), (20, 4, 9, 2), (13, 1, 5, 2), (12, 5, 7, 3), (33, 7, 4, 2), (3, 16, 3, 2),
-                                         (48, 12, 30, 2), (16, 16, 8, 3), (32, 16, 12, 2), (48, 16, 5, 2), (49, 3, 4, 2)])
+                                         (48, 12, 30, 2), (16, 16, 8, 3), (32, 16, 12, 2), (48, 16, 5, 2), (49, 3, 4, 2),
+                                         (64, 16, 40, 2), (57, 9, 5, 3), (64, 1, 3, 2), (50, 16, 1, 2)])
 def test_fp64_beyond_tile16_lds_kernel(lqr, n, m, T, batch):
-    """fp64 inputs outside n <= 12, m <= 4 run the fp64 MFMA tile kernel (n <= 48) or the LDS coverage kernel (beyond): 1e-10."""
+    """fp64 inputs outside n <= 12, m <= 4 run the fp64 MFMA tile kernel: three tile rows with a prefetched operand set up to n = 48,
+    four tile rows without it (PREFETCH = false, lqr_tiled_core.h) for 48 < n <= 64: 1e-10."""
     A, B, Q, R = problems.random_time_varying(batch, T, n, m, seed=50 + n + m, dtype=np.float64)
     Lg = lqr.discreteFiniteHorizonLqr(A, B, Q, R, T)
     Lr = zo.discreteFiniteHorizonLqr(A, B, Q, R, T)
@@ -140,6 +142,35 @@ def test_fp64_lds_kernel_pivoting_and_nonsymmetric(lqr):
     Lg = lqr.discreteFiniteHorizonLqr(A, B, Q, R, T)
     Lr = zo.discreteFiniteHorizonLqr(A, B, Q, R, T)
     assert np.max(np.abs(Lg - Lr)) <= 1e-10 * np.max(np.abs(Lr))
+
+
+def test_fp64_four_tile_rows_pivoting_and_nonsymmetric(lqr):
+    """48 < n <= 64 in fp64 (four tile rows, no prefetched operand set): nonsymmetric Q and a permuted R that forces the pivoted solve."""
+    rng = np.random.default_rng(13)
+    n, m, T, batch = 56, 8, 4, 2
+    A, B, Q, _ = problems.random_time_varying(batch, T, n, m, seed=13, dtype=np.float64)
+    B *= 0.02
+    Q = Q + 0.2 * rng.standard_normal(Q.shape)
+    R = np.roll(np.eye(m), 1, axis=1)[None, None] + 0.01 * rng.standard_normal((batch, T, m, m))
+    Lg = lqr.discreteFiniteHorizonLqr(A, B, Q, R, T)
+    Lr = zo.discreteFiniteHorizonLqr(A, B, Q, R, T)
+    assert np.max(np.abs(Lg - Lr)) <= 1e-10 * np.max(np.abs(Lr))
+
+
+@pytest.mark.parametrize("n,m", [(24, 8), (60, 12)])
+def test_fp64_tile_kernel_and_lds_coverage_kernel_agree(lqr, n, m):
+    """The LDS coverage kernel stays selectable (ZOPT_AMD_LQR_PATH=lds, a product fallback switch): same gains as the tile kernels at
+    three and at four tile rows."""
+    import subprocess, sys, json, os
+    A, B, Q, R = problems.random_time_varying(2, 5, n, m, seed=78)
+    La = lqr.discreteFiniteHorizonLqr(A, B, Q, R, 5)
+    code = ("import numpy as np, json, sys; sys.path.insert(0, %r); from tests import problems; from zopt_amd import lqrUtils;"
+            "A,B,Q,R = problems.random_time_varying(2, 5, %d, %d, seed=78); print(json.dumps(lqrUtils.discreteFiniteHorizonLqr(A,B,Q,R,5).tolist()))"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), n, m))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZOPT_AMD_LQR_PATH="lds"), capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-500:]
+    Lb = np.array(json.loads(out.stdout.strip().splitlines()[-1]))
+    assert np.max(np.abs(La - Lb)) <= 1e-11 * np.max(np.abs(Lb))
 
 
 def test_fp64_tile_kernel_and_lds_kernel_agree(lqr, monkeypatch):

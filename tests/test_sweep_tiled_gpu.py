@@ -1,0 +1,108 @@
+"""GPU parity tests of the large-state sweeps (sweep_tiled_f64.hip): `backwardPass_ilqr` (reference ilqrUtils.py:153-181) and
+`bilinearAffineLqr` (lqrUtils.py:207-262) beyond the tile-16 shapes -- 12 < n <= 48 or 4 < m <= 16, fp64 MFMA tiles -- against the
+oracle at the shapes discreteFiniteHorizonLqr already took: one, two and three 16-wide state tiles, ragged n and m, nonsymmetric
+weights and value Hessians (the reference's formulas do not symmetrise), and a case whose Q_uu needs row exchanges."""
+import numpy as np
+import pytest
+
+from oracle import zopt_oracle as zo
+from tests import problems
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+SHAPES = [(16, 4, 12, 3), (24, 8, 9, 2), (32, 8, 7, 3), (48, 16, 6, 2), (13, 5, 8, 3), (20, 3, 5, 2), (40, 16, 4, 2), (12, 5, 6, 2),
+          (33, 1, 5, 2), (48, 4, 30, 2), (16, 16, 3, 2)]
+
+
+def _rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import torch
+    assert torch.cuda.is_available()
+    from zopt_amd import ilqrUtils, lqrUtils
+    return ilqrUtils, lqrUtils
+
+
+def _nonsym_model(batch, T, n, m, seed):
+    rng = np.random.default_rng(seed + 7)
+    dyn, cost, Vf = problems.random_ilqr_model(batch, T, n, m, seed=seed)
+    c, c_x, c_u, c_xx, c_ux, c_uu = cost
+    v, v_x, v_xx = Vf
+    cost = (c, c_x, c_u, c_xx + 0.2 * rng.standard_normal(c_xx.shape), c_ux, c_uu + 0.2 * rng.standard_normal(c_uu.shape))
+    Vf = (v, v_x, v_xx + 0.2 * rng.standard_normal(v_xx.shape))
+    return dyn, cost, Vf
+
+
+def _oracle_ilqr(dyn, cost, Vf):
+    ls, Ls = [], []
+    for b in range(dyn[1].shape[0]):
+        p = zo.backwardPass_ilqr(zo.AffineDynamics(*(x[b] for x in dyn)), zo.QuadraticCostFunction(*(x[b] for x in cost)),
+                                 zo.QuadraticValueFunction(*(x[b] for x in Vf)))
+        ls.append(p.l)
+        Ls.append(p.L)
+    return np.stack(ls), np.stack(Ls)
+
+
+@pytest.mark.parametrize("nonsym", [False, True])
+@pytest.mark.parametrize("n,m,T,batch", SHAPES)
+def test_backwardPass_ilqr_large_states(mods, n, m, T, batch, nonsym):
+    ilqr = mods[0]
+    seed = 100 * n + 10 * m + T
+    dyn, cost, Vf = _nonsym_model(batch, T, n, m, seed) if nonsym else problems.random_ilqr_model(batch, T, n, m, seed=seed)
+    pol = ilqr.backwardPass_ilqr(dyn, cost, Vf)
+    lr, Lr = _oracle_ilqr(dyn, cost, Vf)
+    assert pol.l.shape == (batch, T, m) and pol.L.shape == (batch, T, m, n)
+    assert _rel(pol.L, Lr) <= RTOL and _rel(pol.l, lr) <= RTOL
+
+
+def test_backwardPass_ilqr_large_states_pivoting_and_torch(mods):
+    """A permuted-dominant nonsymmetric c_uu makes the multipliers of the unpivoted elimination exceed the growth bound: the wave
+    falls back to LU with partial pivoting in LDS -- the arithmetic jnp.linalg.solve performs."""
+    import torch
+    ilqr = mods[0]
+    n, m = 24, 8
+    dyn, cost, Vf = problems.random_ilqr_model(4, 6, n, m, seed=11)
+    c, c_x, c_u, c_xx, c_ux, c_uu = cost
+    P = np.eye(m)[[2, 0, 3, 1, 7, 4, 6, 5]]
+    cost = (c, c_x, c_u, c_xx, c_ux, c_uu @ P * 30.0)
+    lr, Lr = _oracle_ilqr(dyn, cost, Vf)
+    t = lambda tup: tuple(torch.as_tensor(np.asarray(x), device="cuda") for x in tup)
+    pol = ilqr.backwardPass_ilqr(t(dyn), t(cost), t(Vf))
+    assert pol.L.is_cuda
+    assert _rel(pol.L.cpu().numpy(), Lr) <= 1e-9 and _rel(pol.l.cpu().numpy(), lr) <= 1e-9
+
+
+def _affine_problem(batch, T, n, m, seed, nonsym):
+    rng = np.random.default_rng(seed)
+    A, B, Q, R = problems.random_time_varying(batch, T, n, m, seed=seed)
+    if nonsym:
+        Q = Q + 0.3 * rng.standard_normal(Q.shape)
+        R = R + 0.3 * rng.standard_normal(R.shape)
+    d = 0.5 * rng.standard_normal((batch, T, n))
+    H = 0.2 * rng.standard_normal((batch, T, m, n))
+    q = rng.standard_normal((batch, T, n))
+    r = rng.standard_normal((batch, T, m))
+    q0 = rng.standard_normal((batch, T))
+    return A, B, d, Q, R, H, q, r, q0
+
+
+@pytest.mark.parametrize("nonsym", [False, True])
+@pytest.mark.parametrize("n,m,T,batch", SHAPES)
+def test_bilinearAffineLqr_large_states(mods, n, m, T, batch, nonsym):
+    lqr = mods[1]
+    args = _affine_problem(batch, T, n, m, seed=1000 * n + 10 * m + T, nonsym=nonsym)
+    L, l = lqr.bilinearAffineLqr(*args, T)
+    Lr, lr = zo.bilinearAffineLqr(*args, T)
+    assert L.shape == (batch, T, m, n) and l.shape == (batch, T, m)
+    assert _rel(L, Lr) <= RTOL and _rel(l, lr) <= RTOL
+
+
+def test_shapes_beyond_the_tile_kernels_are_refused(mods):
+    ilqr, lqr = mods
+    with pytest.raises(ValueError):
+        lqr.bilinearAffineLqr(*_affine_problem(1, 2, 49, 4, 1, False), 2)
+    with pytest.raises(ValueError):
+        ilqr.backwardPass_ilqr(*problems.random_ilqr_model(1, 2, 16, 17, seed=1))

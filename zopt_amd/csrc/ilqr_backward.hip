@@ -976,10 +976,21 @@ static int launch_ilqr(const double* f_x, const double* f_u, const double* c_x, 
 }
 }  // namespace zm
 
-static int zm_check_sweep_args(const char* who, int64_t batch, int T, int n, int m) {
+namespace zm {
+// sweep_tiled_f64.hip: the iLQR (mode 0) / bilinear-affine (mode 1) sweeps on fp64 MFMA tiles for n <= 48, m <= 16
+int sweep_tiled_f64_dispatch(int mode, const double* f_x, const double* f_u, const double* c_x, const double* c_u, const double* c_xx,
+                             const double* c_ux, const double* c_uu, const double* vf_x, const double* vf_xx, const double* dvec,
+                             long svx, long svxx, const int* active, int shared_hessian, double* l, double* L, int64_t batch, int T,
+                             int n, int m, hipStream_t st, const int* list, long count);
+}  // namespace zm
+
+// tiled: the entry point also has the large-state tile kernel (n <= 48, m <= 16) behind it
+static int zm_check_sweep_args(const char* who, int64_t batch, int T, int n, int m, bool tiled = false) {
     if (batch < 0 || T < 1 || n < 1 || m < 1)
         return zm::set_error(ZM_EINVAL, "%s: bad size batch=%lld T=%d n=%d m=%d", who, (long long)batch, T, n, m);
-    if (n > 12 || m > 4) return zm::set_error(ZM_EUNSUPPORTED, "%s: (n=%d, m=%d) not covered (need n<=12, m<=4)", who, n, m);
+    if (tiled ? (n > 48 || m > 16) : (n > 12 || m > 4))
+        return zm::set_error(ZM_EUNSUPPORTED, "%s: (n=%d, m=%d) not covered (need %s)", who, n, m,
+                             tiled ? "n<=48, m<=16" : "n<=12, m<=4");
     if ((int64_t)T * n * n >= (int64_t)1 << 31 || batch >= ((int64_t)1 << 31))
         return zm::set_error(ZM_EUNSUPPORTED, "%s: T*n*n or batch too large", who);
     return ZM_OK;
@@ -995,8 +1006,12 @@ extern "C" int zm_ilqr_backward_list_f64(const double* f_x, const double* f_u, c
     const zm::TrajList tl{(const int*)list, (long)count};
     if (!f_x || !f_u || !c_x || !c_u || !c_xx || !c_ux || !c_uu || !vf_x || !vf_xx || !l || !L)
         return zm::set_error(ZM_EINVAL, "zm_ilqr_backward_f64: null pointer");
-    const int rc = zm_check_sweep_args("zm_ilqr_backward_f64", batch, T, n, m);
+    const int rc = zm_check_sweep_args("zm_ilqr_backward_f64", batch, T, n, m, true);
     if (rc) return rc;
+    if (n > 12 || m > 4)   // large states: fp64 MFMA tile sweep (sweep_tiled_f64.hip)
+        return zm::sweep_tiled_f64_dispatch(0, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, (long)n, (long)n * n,
+                                            (const int*)active, shared_hessian ? 1 : 0, l, L, batch, T, n, m, (hipStream_t)stream,
+                                            (const int*)list, (long)count);
     if (zm::ilqr_backward_dma_dispatch<0>(f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, (long)n, (long)n * n,
                                        (const int*)active, shared_hessian ? 1 : 0, l, L, batch, T, n, m,
                                        (hipStream_t)stream, tl) == ZM_OK)
@@ -1029,12 +1044,15 @@ extern "C" int zm_lqr_backward_affine_f64(const double* A, const double* B, cons
     if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     if (!A || !B || !d || !Q || !R || !H || !q || !r || !L || !l)
         return zm::set_error(ZM_EINVAL, "zm_lqr_backward_affine_f64: null pointer");
-    const int rc = zm_check_sweep_args("zm_lqr_backward_affine_f64", batch, T, n, m);
+    const int rc = zm_check_sweep_args("zm_lqr_backward_affine_f64", batch, T, n, m, true);
     if (rc) return rc;
     if (batch == 0) return ZM_OK;
     // carry (V, v) <- (Q[T-1], q[T-1])   (lqrUtils.py:261): terminal pointers into the last step, trajectory stride T*size
     const double* vf_xx = Q + (int64_t)(T - 1) * n * n;
     const double* vf_x = q + (int64_t)(T - 1) * n;
+    if (n > 12 || m > 4)   // large states: fp64 MFMA tile sweep (sweep_tiled_f64.hip)
+        return zm::sweep_tiled_f64_dispatch(1, A, B, q, r, Q, H, R, vf_x, vf_xx, d, (long)T * n, (long)T * n * n, nullptr, 0, l, L, batch,
+                                            T, n, m, (hipStream_t)stream, nullptr, 0);
     if (zm::ilqr_backward_dma_dispatch<1>(A, B, q, r, Q, H, R, vf_x, vf_xx, d, (long)T * n, (long)T * n * n, nullptr, 0, l, L,
                                           batch, T, n, m, (hipStream_t)stream) == ZM_OK)
         return ZM_OK;

@@ -257,7 +257,10 @@ __device__ unsigned long long zm_tiled_stamps[12];
 #define ZT_STAMP(i)
 #endif
 
-template <class TR, int NT, bool EXACT>
+// PREFETCH: the operands of step k-1 are fetched into a second register set (Fn, Rn) while step k computes.  false (fp64 at four tile
+// rows, where V + F + Y alone take 448 of the 512 registers): the step's operands are loaded at its head instead -- the HBM latency
+// of one step's loads is exposed once per ~20 us step, which costs far less than spilling a second operand set.
+template <class TR, int NT, bool EXACT, bool PREFETCH = true>
 __global__ __launch_bounds__(64) void lqr_backward_tiled(const typename TR::S* __restrict__ A, const typename TR::S* __restrict__ B,
                                                          const typename TR::S* __restrict__ Q, const typename TR::S* __restrict__ R,
                                                          typename TR::S* __restrict__ L, const long batch, const int T, const int n_,
@@ -286,29 +289,39 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled(const typename TR::S* _
     const S* Rb = R + traj * T * mm;
     S* Lb = L + traj * T * nm;
 
-    f4 V[NT][NT], F[NT][NT + 1], Fn[NT][NT + 1], Y[NT][NT + 1], Rt, Rn;
+    f4 V[NT][NT], F[NT][NT + 1], Fn[PREFETCH ? NT : 1][NT + 1], Y[NT][NT + 1], Rt, Rn;
     // terminal value = last stage cost (lqrUtils.py:172); operands of the first step
 #pragma unroll
     for (int K = 0; K < NT; ++K) {
 #pragma unroll
         for (int J = 0; J < NT; ++J) {
             V[K][J] = load_tile<TR, EXACT>(Qb + (long)(T - 1) * nn, n, n, K, J, g, c);
-            Fn[K][J] = load_tile<TR, EXACT>(Ab + (long)(T - 1) * nn, n, n, K, J, g, c);
+            if constexpr (PREFETCH) Fn[K][J] = load_tile<TR, EXACT>(Ab + (long)(T - 1) * nn, n, n, K, J, g, c);
         }
-        Fn[K][NT] = load_tile<TR, EXACT>(Bb + (long)(T - 1) * nm, n, m, K, 0, g, c);
+        if constexpr (PREFETCH) Fn[K][NT] = load_tile<TR, EXACT>(Bb + (long)(T - 1) * nm, n, m, K, 0, g, c);
     }
-    Rn = load_tile<TR, EXACT>(Rb + (long)(T - 1) * mm, m, m, 0, 0, g, c, S(1));
+    if constexpr (PREFETCH) Rn = load_tile<TR, EXACT>(Rb + (long)(T - 1) * mm, m, m, 0, 0, g, c, S(1));
 
 #ifdef ZM_TILED_LAB
     unsigned long long zt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, zt_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(zt_last)::"memory");
 #endif
     for (int k = T - 1; k >= 0; --k) {
+        if constexpr (PREFETCH) {
 #pragma unroll
-        for (int K = 0; K < NT; ++K)
+            for (int K = 0; K < NT; ++K)
 #pragma unroll
-            for (int J = 0; J <= NT; ++J) F[K][J] = Fn[K][J];
-        Rt = Rn;
+                for (int J = 0; J <= NT; ++J) F[K][J] = Fn[K][J];
+            Rt = Rn;
+        } else {
+#pragma unroll
+            for (int K = 0; K < NT; ++K) {
+#pragma unroll
+                for (int J = 0; J < NT; ++J) F[K][J] = load_tile<TR, EXACT>(Ab + k * nn, n, n, K, J, g, c);
+                F[K][NT] = load_tile<TR, EXACT>(Bb + k * nm, n, m, K, 0, g, c);
+            }
+            Rt = load_tile<TR, EXACT>(Rb + k * mm, m, m, 0, 0, g, c, S(1));
+        }
         ZT_STAMP(0)   // loop head: waits for the operands of this step (issued during the previous step)
         // Y_B = V^T B
 #pragma unroll
@@ -530,8 +543,8 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled(const typename TR::S* _
 #pragma unroll
             for (int r = 0; r < 4; ++r) NL[J][r] = Sc[(16 * J + c) * TLD + TR::row(g, r)];
         ZT_STAMP(4)   // L store, -L through LDS back as tiles
-        {  // operands of step k-1, fetched under the ~15k cycles of MFMAs that follow (the last iteration re-reads step 0:
-           // no branch around the loads); issued only now so that they do not hold 84 registers during the solve
+        if constexpr (PREFETCH) {  // operands of step k-1, fetched under the ~15k cycles of MFMAs that follow (the last iteration
+           // re-reads step 0: no branch around the loads); issued only now so that they do not hold 84 registers during the solve
             const int kn = k > 0 ? k - 1 : 0;
 #pragma unroll
             for (int K = 0; K < NT; ++K) {
@@ -582,16 +595,16 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled(const typename TR::S* _
 }
 
 
-template <class TR, int NT>
+template <class TR, int NT, bool PREFETCH = true>
 static int launch_tiled(const typename TR::S* A, const typename TR::S* B, const typename TR::S* Q, const typename TR::S* R,
                         typename TR::S* L, int64_t batch, int T, int n, int m, hipStream_t st) {
     const bool exact = (n == 16 * NT) && (m == 16) && !zm::lab_env("ZOPT_AMD_TILED_GENERIC");
     if (exact)
-        hipLaunchKernelGGL((lqr_backward_tiled<TR, NT, true>), dim3((unsigned)batch), dim3(64), 0, st, A, B, Q, R, L, (long)batch, T, n,
-                           m);
+        hipLaunchKernelGGL((lqr_backward_tiled<TR, NT, true, PREFETCH>), dim3((unsigned)batch), dim3(64), 0, st, A, B, Q, R, L,
+                           (long)batch, T, n, m);
     else
-        hipLaunchKernelGGL((lqr_backward_tiled<TR, NT, false>), dim3((unsigned)batch), dim3(64), 0, st, A, B, Q, R, L, (long)batch, T,
-                           n, m);
+        hipLaunchKernelGGL((lqr_backward_tiled<TR, NT, false, PREFETCH>), dim3((unsigned)batch), dim3(64), 0, st, A, B, Q, R, L,
+                           (long)batch, T, n, m);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }
