@@ -139,6 +139,12 @@ int rollout_fast_dispatch(const zm_model_t& md, const double* Q, const double* R
 
 }  // namespace zm
 
+namespace zm {
+int rollout_wide_dispatch(const zm_model_t& md, const zm_quadcost_t* cost, const double* x0, const double* l, const double* L,
+                          const double* xPrev, const double* uPrev, const double* alphas, int n_alpha, const int* active,
+                          const int* list, long count, double* xTraj, double* uTraj, double* J, int* idx, long batch, int T,
+                          hipStream_t st);   // rollout_wide.hip
+}
 static int rollout_impl(const zm_model_t* model, const zm_quadcost_t* cost, const double* x0,
                                          const double* l, const double* L, const double* xPrev, const double* uPrev,
                                          const double* alphas, int n_alpha, const int32_t* active, const int32_t* list,
@@ -162,12 +168,20 @@ static int rollout_impl(const zm_model_t* model, const zm_quadcost_t* cost, cons
     } else {
         return zm::set_error(ZM_EUNSUPPORTED, "zm_rollout_linesearch_f64: unknown model kind %d", md.kind);
     }
-    if (md.n < 1 || md.n > zm::MAXN || md.m < 1 || md.m > zm::MAXM)
-        return zm::set_error(ZM_EUNSUPPORTED, "zm_rollout_linesearch_f64: (n=%d, m=%d) not covered (n<=12, m<=4)", md.n, md.m);
+    const bool wide = md.kind == ZM_MODEL_LINEAR && (md.n > zm::MAXN || md.m > zm::MAXM) && md.n >= 1 && md.m >= 1 && md.n <= 64 &&
+                      md.m <= 16;   // large linear models: one wave per rollout (rollout_wide.hip)
+    if (!wide && (md.n < 1 || md.n > zm::MAXN || md.m < 1 || md.m > zm::MAXM))
+        return zm::set_error(ZM_EUNSUPPORTED, "zm_rollout_linesearch_f64: (n=%d, m=%d) not covered (n<=12, m<=4; linear models n<=64, m<=16)",
+                             md.n, md.m);
     if (cost && (!cost->Q || !cost->R || !cost->Qf))
         return zm::set_error(ZM_EINVAL, "zm_rollout_linesearch_f64: cost needs Q, R, Qf");
     if (batch == 0 || (list && count == 0)) return ZM_OK;
     if (count < 0 || count > batch) return zm::set_error(ZM_EINVAL, "zm_rollout_linesearch: bad list length");
+    if (wide) {
+        if (scratch) return zm::set_error(ZM_EUNSUPPORTED, "rollout: all-store mode needs the fast path");
+        return zm::rollout_wide_dispatch(md, cost, x0, l, L, xPrev, uPrev, alphas, n_alpha, (const int*)active, (const int*)list,
+                                         (long)count, xTraj, uTraj, J, (int*)alpha_idx, (long)batch, T, (hipStream_t)stream);
+    }
     if (scratch && !(n_alpha == 16 && list && alpha_idx && J)) return zm::set_error(ZM_EINVAL, "rollout: all-store mode needs 16 step sizes, a list, J and alpha_idx");
     const int64_t nslot = list ? count : batch;
     hipStream_t st = (hipStream_t)stream;
