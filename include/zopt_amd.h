@@ -173,7 +173,7 @@ typedef struct zm_quadcost_t {
  * in : x0 (batch,n)  l (batch,T,m)  L (batch,T,m,n)  xPrev (batch,T+1,n)  uPrev (batch,T,m)  alphas (n_alpha) [device]
  *      active (batch) int32 or NULL: trajectories with active==0 are skipped (their outputs are left untouched)
  * out: xTraj (batch,T+1,n)  uTraj (batch,T,m)  J (batch) or NULL  alpha_idx (batch) int32 or NULL
-  * Shapes: registered models with n <= 12, m <= 4 (one lane per rollout; the (12, 4) fast paths of rollout_fast.hip / rollout_quad.hip);
+ * Shapes: registered models with n <= 12, m <= 4 (one lane per rollout; the (12, 4) fast paths of rollout_fast.hip / rollout_quad.hip);
  *      ZM_MODEL_LINEAR also beyond, up to n <= 64, m <= 16 (rollout_wide.hip: one wave per rollout, lane i owns state i; four waves
  *      per trajectory share the 16 step sizes, the winner is rolled out once more with stores; no scratch).
  */
