@@ -336,6 +336,11 @@ int zm_condition_dynamics_f64(const double* f_xx, const double* f_ux, const doub
 #define ZM_MPC_OPTIMAL 1            /* cvxpy status "optimal"            */
 #define ZM_MPC_INFEASIBLE 2         /* "infeasible"                      */
 #define ZM_MPC_USER_LIMIT 3         /* "user_limit" (max_iter reached)   */
+#define ZM_MPC_OPTIMAL_INACCURATE 4 /* "optimal_inaccurate": max_iter reached with both residuals within 10x their tolerances -- OSQP's
+                                       "solved inaccurate", which cvxpy reports under this name (mpcUtils.py:74,78).  The rest of cvxpy's
+                                       vocabulary cannot arise here: "unbounded" needs a direction of unbounded descent, which a cost
+                                       with Q, Qf >= 0 and R > 0 over dynamics-feasible trajectories does not have, and
+                                       "infeasible_inaccurate" is reported as "user_limit" (an uncertified instance at the cap) */
 
 /* Riccati tables of the ADMM w-update for penalty rho:  K (N,m,n), Minv (N,m,m)   [all device pointers]
  * in : A (n,n) B (n,m) Q (n,n) R (m,m) Qf (n,n) */

@@ -185,7 +185,7 @@ def test_receding_horizon_loop(mpc):
         x = np.clip(x, -x_ub + 1e-6, x_ub - 1e-6)
         u, traj, status = prob.solve(x, solver="OSQP", eps_prim_inf=1e-3, eps_dual_inf=1e-3, eps_abs=1e-2, eps_rel=1e-2,
                                      max_iter=2000, warm_start=False)      # the demo's options (demos/lqrMpc.py:32)
-        assert set(status[alive]) <= {"optimal", "infeasible", "user_limit"}
+        assert set(status[alive]) <= {"optimal", "optimal_inaccurate", "infeasible", "user_limit"}
         for b in np.where(alive & (status == "infeasible"))[0][:2]:
             if checked < 4:
                 assert not _lp_feasible(A, B, Q, R, Qf, 25, x_ub, u_ub, x[b])
@@ -194,6 +194,27 @@ def test_receding_horizon_loop(mpc):
         x = np.where(alive[:, None], traj.xTraj[:, 1], x)
     assert alive.sum() >= 16
     assert np.all(np.linalg.norm(x[alive, 9:12], axis=1) < d0[alive])      # every surviving instance moved towards the origin
+
+
+def test_status_vocabulary_at_the_iteration_limit(mpc):
+    """cvxpy's names for OSQP's outcomes at `max_iter` (mpcUtils.py:74,78): "optimal_inaccurate" (OSQP "solved inaccurate") when both
+    residuals are within 10x their tolerances, "user_limit" otherwise; with enough iterations the same instances are "optimal".  The
+    residuals the kernel reports (`last_residuals`) decide which."""
+    prob, (A, B, Q, R, Qf, x_ub, u_ub) = _quad_mpc(mpc, N=25)
+    rng = np.random.default_rng(4)
+    x = np.zeros((64, 12))
+    x[:, 9:12] = rng.uniform(-10, 10, (64, 3))
+    _, _, full = prob.solve(x, eps_abs=1e-3, eps_rel=1e-3, max_iter=4000, warm_start=False)
+    its = prob.last_iterations.copy()
+    assert np.all(full == "optimal")
+    seen = set()
+    for cap in (5, 15, 30, 60):
+        _, _, st = prob.solve(x, eps_abs=1e-3, eps_rel=1e-3, max_iter=cap, warm_start=False)
+        assert set(st) <= {"optimal", "optimal_inaccurate", "user_limit"}
+        assert np.all((st == "optimal") == (its <= cap))               # the cap only cuts the iteration short
+        assert np.all(prob.last_iterations[st != "optimal"] == cap)
+        seen |= set(st)
+    assert {"optimal_inaccurate", "user_limit"} <= seen
 
 
 def test_warm_start_reuses_previous_iterates(mpc):

@@ -174,6 +174,7 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const double* __restrict_
     int status = x0_ok ? 0 : ZM_MPC_INFEASIBLE;
     int it = 0;  // this lane's ADMM iterations
     double rp = 0.0, rd = 0.0;
+    bool near_ok = false;   // the last iterate's residuals are within 10x the tolerances (OSQP's "solved inaccurate" test at the cap)
     bool done = !live || status != 0;
     for (int gi = 0; gi < g.max_iter; ++gi) {  // gi is wave-uniform
         if (__all(done)) break;
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const double* __restrict_
             rd = rho * nrd;
             const double ep = g.eps_abs + g.eps_rel * __builtin_fmax(nw, ny);
             const double ed = g.eps_abs + g.eps_rel * rho * nl;
+            near_ok = (rp <= 10.0 * ep) && (rd <= 10.0 * ed);
             if (rp <= ep && rd <= ed) {
                 status = ZM_MPC_OPTIMAL;
                 done = true;
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const double* __restrict_
                 g.xTraj[(ii * (N + 1) + k + 1) * NS + i] = x[i];
             }
         }
-        g.status[ii] = status ? status : ZM_MPC_USER_LIMIT;
+        g.status[ii] = status ? status : (near_ok ? ZM_MPC_OPTIMAL_INACCURATE : ZM_MPC_USER_LIMIT);
         okflag[ii] = (status == ZM_MPC_OPTIMAL) ? 1.0 : 0.0;
         if (g.iters) g.iters[ii] = it;
         if (g.resid) {

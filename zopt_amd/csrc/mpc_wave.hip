@@ -190,6 +190,7 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
     int status = x0_in ? 0 : ZM_MPC_INFEASIBLE;
     int it = 0;
     double rp = 0.0, rd = 0.0;
+    bool near_ok = false;   // the last iterate's residuals are within 10x the tolerances (OSQP's "solved inaccurate" test at the cap)
     bool done = !live || status != 0;              // group-uniform
     for (int gi = 0; gi < g.max_iter; ++gi) {
         if (__all(done)) break;
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
             rd = rho * nrd;
             const double ep = g.eps_abs + g.eps_rel * __builtin_fmax(nw, ny);
             const double ed = g.eps_abs + g.eps_rel * rho * nl;
+            near_ok = (rp <= 10.0 * ep) && (rd <= 10.0 * ed);
             if (rp <= ep && rd <= ed) {
                 status = ZM_MPC_OPTIMAL;
                 done = true;
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
             }
         }
         if (li == 0) {
-            g.status[inst] = status ? status : ZM_MPC_USER_LIMIT;
+            g.status[inst] = status ? status : (near_ok ? ZM_MPC_OPTIMAL_INACCURATE : ZM_MPC_USER_LIMIT);
             *okflag = (status == ZM_MPC_OPTIMAL) ? 1.0 : 0.0;
             okflag[1] = (double)lvl;
             if (g.iters) g.iters[inst] = it;

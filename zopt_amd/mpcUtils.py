@@ -19,7 +19,10 @@ try:
 except Exception:  # pragma: no cover
     torch = None
 
-_STATUS = {1: "optimal", 2: "infeasible", 3: "user_limit"}
+# cvxpy's status strings (mpcUtils.py:74,78).  "optimal_inaccurate" = OSQP's "solved inaccurate": the iteration limit was reached with
+# both residuals within 10x their tolerances.  "unbounded" cannot arise for this QP (Q, Qf >= 0, R > 0); an instance that is neither
+# solved nor certified infeasible at the limit is "user_limit" (cvxpy's name for OSQP's "maximum iterations reached").
+_STATUS = {1: "optimal", 2: "infeasible", 3: "user_limit", 4: "optimal_inaccurate"}
 
 
 class lqrMpc():
@@ -124,7 +127,7 @@ class lqrMpc():
         -------
             u : Optimal control at current time step (…, m)
             traj : Trajectory tuple (xTraj (…, N+1, n), uTraj (…, N, m))
-            status : problem status, one of [optimal, infeasible, user_limit] (a list of them for a batch)
+            status : problem status, one of [optimal, optimal_inaccurate, infeasible, user_limit] (a list of them for a batch)
         """
         solver = kwargs.pop("solver", None)
         if solver not in (None, "OSQP"):
