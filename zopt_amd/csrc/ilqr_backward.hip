@@ -259,7 +259,7 @@ __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], 
     const double quu_a = sm[oqa];  // Q_uu[c][g]: A operand of Q_uu L (0-padded through the address choice below)
     __builtin_amdgcn_wave_barrier();
     const double b0[4] = {b[0], b[1], b[2], b[3]};  // original right-hand side (Sux column) for MODE 1's v' update
-    if (__builtin_amdgcn_ballot_w64(!lu_solve4_nopivot(S, b, x)) != 0ull) lu_solve4(S, b, x);
+    if (__builtin_amdgcn_ballot_w64(!lu_solve4_nopivot(S, b, x)) != 0ull) lu_solve4_fallback(S, b, x);
     const double x01 = (g & 1) ? x[1] : x[0];
     const double x23 = (g & 1) ? x[3] : x[2];
     const double xg = (g & 2) ? x23 : x01;

@@ -23,8 +23,11 @@ namespace zm {
 
 // Stable compaction of the active ids (ascending trajectory order, as torch.nonzero gave the Python loop): one block, one
 // ballot-scan pass per 1024 trajectories.  count[0] <- number of active trajectories.
+// hostword (pinned host memory, may be null): <- (seq << 32 | count) as ONE 8-byte system-scope store -- the host side of the solve
+// polls it instead of waiting for a copy kernel, an event and the interrupt behind hipEventSynchronize (~45 us per round trip).
 __global__ __launch_bounds__(1024) void compact_active_kernel(const int* __restrict__ active, const long batch, int* __restrict__ list,
-                                                              int* __restrict__ count) {
+                                                              int* __restrict__ count, unsigned long long* hostword,
+                                                              const unsigned seq) {
     __shared__ int wsum[16];
     __shared__ int base;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -48,7 +51,32 @@ __global__ __launch_bounds__(1024) void compact_active_kernel(const int* __restr
         }
         __syncthreads();
     }
-    if (tid == 0) count[0] = base;
+    if (tid == 0) {
+        count[0] = base;
+        if (hostword) __hip_atomic_store(hostword, ((unsigned long long)seq << 32) | (unsigned)base, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// Start of a solve in ONE launch (it was seven memset / memcpy / fill calls, each a runtime call of its own on the host):
+// l <- uGuess, L <- 0 (policy0 = (uGuess, 0), ilqrUtils.py:293), previous trajectory <- 0 (:294), alphas <- 0.5 ** arange(16) (:145),
+// active <- 1, converged <- 0, where <- 0.
+__global__ __launch_bounds__(256) void ilqr_init_kernel(double* __restrict__ l, const double* __restrict__ uGuess, const long nl,
+                                                        double* __restrict__ L, const long nL, double* __restrict__ xT2, const long nx,
+                                                        double* __restrict__ uT2, double* __restrict__ alphas, int* __restrict__ active,
+                                                        int* __restrict__ converged, int* __restrict__ where, const long batch) {
+    const long stride = (long)gridDim.x * blockDim.x, t0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    for (long i = t0; i < nL; i += stride) L[i] = 0.0;
+    for (long i = t0; i < nx; i += stride) xT2[i] = 0.0;
+    for (long i = t0; i < nl; i += stride) {
+        l[i] = uGuess[i];
+        uT2[i] = 0.0;
+    }
+    for (long i = t0; i < batch; i += stride) {
+        active[i] = 1;
+        converged[i] = 0;
+        if (where) where[i] = 0;
+    }
+    if (t0 < 16) alphas[t0] = 1.0 / (double)(1u << t0);   // exact powers of two
 }
 
 __global__ void fill_i32_kernel(int* __restrict__ p, const long n, const int v) {
@@ -147,9 +175,10 @@ static IlqrWs carve(const zm_model_t* model, long b, long T, int ddp, int need_u
 // Pool of (pinned int32, event) pairs per device for the drivers' host round trips.
 struct HostSlot {
     int dev;
-    int32_t* word;
+    unsigned long long* word;   // pinned: (seq << 32 | count), written by compact_active_kernel
     hipEvent_t event;
     bool busy;
+    unsigned seq;               // last sequence number handed out for this word
 };
 static std::mutex g_slot_mutex;
 static std::vector<HostSlot> g_slots;
@@ -166,8 +195,9 @@ class HostSlotLease {
                 event_ = g_slots[i].event;
                 return;
             }
-        HostSlot s{dev, nullptr, nullptr, true};
-        if (hipHostMalloc((void**)&s.word, sizeof(int32_t), hipHostMallocDefault) != hipSuccess) return;
+        HostSlot s{dev, nullptr, nullptr, true, 0u};
+        if (hipHostMalloc((void**)&s.word, sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) return;
+        *s.word = 0ull;
         if (hipEventCreateWithFlags(&s.event, hipEventDisableTiming) != hipSuccess) {
             (void)hipHostFree(s.word);
             return;
@@ -183,14 +213,37 @@ class HostSlotLease {
         if ((size_t)idx_ < g_slots.size() && g_slots[idx_].word == word_) g_slots[idx_].busy = false;
     }
     bool ok() const { return idx_ >= 0; }
-    int32_t* word() const { return word_; }
+    unsigned long long* word() const { return word_; }
     hipEvent_t event() const { return event_; }
+    unsigned next_seq() {   // a fresh tag per round trip (never 0: the word starts as 0)
+        std::lock_guard<std::mutex> lk(g_slot_mutex);
+        unsigned& q = g_slots[idx_].seq;
+        q = (q == 0xffffffffu) ? 1u : q + 1u;
+        return q;
+    }
 
   private:
     long idx_;
-    int32_t* word_ = nullptr;
+    unsigned long long* word_ = nullptr;
     hipEvent_t event_ = nullptr;
 };
+
+// Waits until the device has published (seq, count) in the pinned word; returns count.  Busy-polls (the answer is a few
+// microseconds away: one small kernel behind what is already queued); after `spin_limit` polls without it -- a slow or
+// profiled run -- it falls back to the event behind the kernel and the device-side copy of the count.
+static int wait_for_count(const unsigned long long* word, const unsigned seq, hipEvent_t ev, const int32_t* dcount, int32_t* out) {
+    for (long spin = 0; spin < 20000000L; ++spin) {
+        const unsigned long long v = __atomic_load_n(word, __ATOMIC_ACQUIRE);
+        if ((unsigned)(v >> 32) == seq) {
+            *out = (int32_t)(unsigned)(v & 0xffffffffull);
+            return ZM_OK;
+        }
+        __builtin_ia32_pause();
+    }
+    ZM_HIP_CHECK(hipEventSynchronize(ev));
+    ZM_HIP_CHECK(hipMemcpy(out, dcount, sizeof(int32_t), hipMemcpyDeviceToHost));
+    return ZM_OK;
+}
 
 // zm_shutdown(): frees every pair that is not lent out; returns how many were released.
 int release_host_slots() {
@@ -250,14 +303,15 @@ static int ilqr_solve_impl(const zm_model_t* model, const zm_quadcost_t* cost, c
     int32_t* dcount = iwork + 2 * batch;
     const long xrow = (long)(T + 1) * n, urow = (long)T * m;
 
-    // policy = (uGuess, 0); traj_prev = zeros                                                        (ilqrUtils.py:293-294)
-    ZM_HIP_CHECK(hipMemcpyAsync(ws + w.l, uGuess, sizeof(double) * batch * urow, hipMemcpyDeviceToDevice, st));
-    ZM_HIP_CHECK(hipMemsetAsync(L, 0, sizeof(double) * batch * urow * n, st));
-    ZM_HIP_CHECK(hipMemsetAsync(ws + w.xT2, 0, sizeof(double) * batch * xrow, st));
-    ZM_HIP_CHECK(hipMemsetAsync(ws + w.uT2, 0, sizeof(double) * batch * urow, st));
-    hipLaunchKernelGGL(zm::fill_alphas_kernel, dim3(1), dim3(16), 0, st, ws + w.alphas);   // 0.5 ** arange(16) (:145), no host round trip
-    hipLaunchKernelGGL(zm::fill_i32_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, active, (long)batch, 1);
-    ZM_HIP_CHECK(hipMemsetAsync(converged, 0, sizeof(int32_t) * batch, st));
+    // policy = (uGuess, 0); traj_prev = zeros; step sizes; masks                                     (ilqrUtils.py:293-294, :145)
+    int32_t* where = (int32_t*)(ws + w.where);
+    {
+        const long nL = (long)batch * urow * n, nx = (long)batch * xrow, nl = (long)batch * urow;
+        const long work = nL > nx ? nL : nx;
+        const unsigned blocks = (unsigned)((work + 256L * 8 - 1) / (256L * 8) < 4096 ? (work + 256L * 8 - 1) / (256L * 8) : 4096);
+        hipLaunchKernelGGL(zm::ilqr_init_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, ws + w.l, uGuess, nl, L, nL, ws + w.xT2, nx,
+                           ws + w.uT2, ws + w.alphas, (int*)active, (int*)converged, (int*)where, (long)batch);
+    }
     // initial rollout (alpha = 1) from the zero trajectory and its cost                                (:297-298)
     int rc = zm_rollout_linesearch_f64(model, cost, x0, ws + w.l, L, ws + w.xT2, ws + w.uT2, ws + w.alphas, 1, nullptr, xTraj, uTraj, J,
                                        nullptr, batch, T, st);
@@ -304,7 +358,7 @@ static int ilqr_solve_impl(const zm_model_t* model, const zm_quadcost_t* cost, c
     ZM_HIP_CHECK(hipGetDevice(&dev));
     zm::HostSlotLease lease(dev);
     if (!lease.ok()) return zm::set_error(ZM_EUNSUPPORTED, "zm_ilqr_solve_f64: cannot get a pinned word / event on device %d", dev);
-    int32_t* const hcount_pinned = lease.word();
+    unsigned long long* const hword = lease.word();
     const hipEvent_t count_ready = lease.event();
     // The trajectories alternate between two buffers: the two-pass line search reads the current rows (xPrev, uPrev) and writes the
     // winner's into the other buffer, which then IS the current one -- the acceptance step copies nothing (it was 212 MB per
@@ -315,8 +369,6 @@ static int ilqr_solve_impl(const zm_model_t* model, const zm_quadcost_t* cost, c
         const char* e = zm::lab_env("ZOPT_AMD_ILQR_SWAP");
         return !(e && e[0] == '0');
     }();
-    int32_t* where = (int32_t*)(ws + w.where);
-    if (swap_on) ZM_HIP_CHECK(hipMemsetAsync(where, 0, sizeof(int32_t) * batch, st));
     double *curX = xTraj, *curU = uTraj, *altX = ws + w.xT2, *altU = ws + w.uT2;
     int it = 0;
     int64_t count = batch;
@@ -327,19 +379,22 @@ static int ilqr_solve_impl(const zm_model_t* model, const zm_quadcost_t* cost, c
         // the same values into the same rows), and the host round trip (~45 us) passes while it runs.
         // (Measured: a longer interval once the active set is small does not pay -- a stale list costs the DDP tail 1-3 %.)
         const bool sync_now = (it % sync_every == 0);
+        unsigned seq = 0;
         if (sync_now) {
+            seq = lease.next_seq();
             hipLaunchKernelGGL(zm::compact_active_kernel, dim3(1), dim3(1024), 0, st, (const int*)active, (long)batch, (int*)list,
-                               (int*)dcount);
-            ZM_HIP_CHECK(hipMemcpyAsync(hcount_pinned, dcount, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            ZM_HIP_CHECK(hipEventRecord(count_ready, st));
+                               (int*)dcount, hword, seq);
+            ZM_HIP_CHECK(hipEventRecord(count_ready, st));   // only waited for if the pinned word does not show up (wait_for_count)
         }
         // expansions along the current trajectories: [f_x | f_u], c_x, c_u, v_x in one launch                  (:304-313)
         rc = zm::expand_list(model, cost, curX, curU, list, count, active, ws + w.f_x, ws + w.f_u, ws + w.c_x, ws + w.c_u,
                              ws + w.v_x, batch, T, st, packed ? 1 : 0);
         if (rc) return rc;
         if (sync_now) {
-            ZM_HIP_CHECK(hipEventSynchronize(count_ready));
-            count = *hcount_pinned;
+            int32_t c32 = 0;
+            rc = zm::wait_for_count(hword, seq, count_ready, dcount, &c32);
+            if (rc) return rc;
+            count = c32;
             if (count == 0) break;
         }
         if (packed) {

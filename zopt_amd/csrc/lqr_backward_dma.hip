@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64 * W, WPS) void lqr_backward_dma_f64(const IO* __
             // wave-uniform vote on the scalar unit: "some lane failed the growth check" = ballot(!ok) != 0
             if (__builtin_amdgcn_ballot_w64(!lu_solve4_nopivot(S, b, x)) != 0ull) {
                 // rare: growth check failed somewhere in the wave -> partial pivoting, IEEE division
-                lu_solve4(S, b, x);
+                lu_solve4_fallback(S, b, x);
             }
             if constexpr (((X >> 21) & 1) != 0) __builtin_amdgcn_wave_barrier();
             const double x01 = (g & 1) ? x[1] : x[0];

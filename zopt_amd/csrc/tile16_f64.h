@@ -117,4 +117,24 @@ __device__ __forceinline__ bool lu_solve4_nopivot(const double (&S)[4][4], const
     return ok;
 }
 
+// The re-solve after a failed growth check, shared by the sweep kernels: LU with partial pivoting -- unless S holds a NaN.  Then
+// every component of the solution is NaN whichever elimination order runs (a NaN row update f * S[k][j] poisons its whole row even
+// through zeros, a NaN pivot poisons every row below it, and the back substitution multiplies every x_j into the rows above it), so
+// the result is written directly.  This matters for speed, not for values: an iLQR start that has diverged to NaN (0.9 % of
+// BASELINE configs[3]'s starts, which the reference keeps iterating to maxIter) would otherwise take the slow pivoted path in every
+// step of every remaining sweep -- and a launch lasts as long as its slowest wave (tail sweeps: 109 instead of 77 us).
+__device__ __forceinline__ void lu_solve4_fallback(double (&S)[4][4], double (&b)[4], double (&x)[4]) {
+    bool has_nan = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) has_nan |= (S[i][j] != S[i][j]);
+    if (has_nan) {
+        const double qnan = __builtin_nan("");
+        x[0] = x[1] = x[2] = x[3] = qnan;
+    } else {
+        lu_solve4(S, b, x);
+    }
+}
+
 }  // namespace zm
