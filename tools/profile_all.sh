@@ -18,7 +18,8 @@ run() {  # name, script args...
 run bench     $R/bench.py --no-cpu-baseline --no-secondary
 run ilqr      $R/tools/bench_ilqr.py --reps 1
 run mpc       $R/tools/bench_mpc.py --eps 1e-2
-run tiled     $R/tools/bench_lqr_tiled.py --batch 2048 --reps 2
+run tiled     $R/tools/bench_lqr_tiled.py --batch 2048 --reps 14     # >= 10 launches: the average is a steady-state one, not a cold-clock sample
+run wide      $R/tools/bench_sweep_tiled.py --reps 6
 run sweeps    $R/tools/bench_ilqr_backward.py --reps 3
 run ddp       $R/tools/bench_ilqr.py --ddp --reps 1
 run psd       $R/tools/bench_psd.py
