@@ -305,7 +305,10 @@ int zm_quadcopter_trim_f64(const double* uvw, const double* wind_body, double* x
 
 /* Batched projection onto the positive definite cone: A <- V max(w, eps) V^T with (w, V) = eigh((A + A^T)/2).
  * Replaces: zopt/ilqrUtils.py:217-219 ensurePositiveDefinite (jnp.linalg.eigh symmetrises its input) and its users
- *           :254-257 conditionValueFunction (k = n).       in/out: A (count,k,k) in place, k <= 16.
+ *           :254-257 conditionValueFunction (k = n).       in/out: A (count,k,k) in place, k <= 64: one wave per matrix, matrix-sign
+ *           iterations on fp64 MFMA tiles instead of an eigen-decomposition -- one 16 x 16 tile up to k = 16 (psd.hip, ns16.h), NT x NT
+ *           tiles beyond (psd_tiled.hip; the same iteration, constants and caps).  zm_condition_cost_f64 likewise for n + m <= 64;
+ *           zm_condition_dynamics_f64 (the DDP path) stays at n + m <= 16.
  */
 int zm_psd_project_f64(double* A, int64_t count, int k, double eps, void* stream);
 

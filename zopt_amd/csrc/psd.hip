@@ -12,73 +12,10 @@
 // sweep at most), or after 20 sweeps.
 #include "jacobi16.h"
 #include "ns16.h"
+#include "psd_mats.h"
 #include "zm_common.h"
 
 namespace zm {
-
-// element accessors of the (possibly block-stored) symmetric matrix
-struct PlainMat {
-    double* A;
-    int k;
-    __device__ __forceinline__ double load(long mat, int i, int j) const { return A[(mat * k + i) * k + j]; }
-    __device__ __forceinline__ void store(long mat, int i, int j, double v) const { A[(mat * k + i) * k + j] = v; }
-};
-struct StackedCost {  // [[c_xx, c_ux^T],[c_ux, c_uu]]   (ilqrUtils.py:230)
-    double *cxx, *cux, *cuu;
-    int n, m;
-    __device__ __forceinline__ double load(long mat, int i, int j) const {
-        if (i < n) return (j < n) ? cxx[(mat * n + i) * n + j] : cux[(mat * m + (j - n)) * n + i];
-        return (j < n) ? cux[(mat * m + (i - n)) * n + j] : cuu[(mat * m + (i - n)) * m + (j - n)];
-    }
-    __device__ __forceinline__ void store(long mat, int i, int j, double v) const {
-        // ilqrUtils.py:232: c_xx = zz[:n,:n], c_uu = zz[-m:,-m:], c_ux = zz[-m:,:n]   (the upper-right block is dropped)
-        if (i < n) {
-            if (j < n) cxx[(mat * n + i) * n + j] = v;
-        } else {
-            if (j < n)
-                cux[(mat * m + (i - n)) * n + j] = v;
-            else
-                cuu[(mat * m + (i - n)) * m + (j - n)] = v;
-        }
-    }
-};
-
-// vf_zz = sum_l v_x[l] * d2f_l/dz2, stacked as [[vf_xx, vf_ux^T],[vf_ux, vf_uu]]   (ilqrUtils.py:240-247); the projected blocks go
-// to separate outputs (:249)
-struct ContractedDynamics {
-    const double *f_xx, *f_ux, *f_uu, *v_x;
-    double *o_xx, *o_ux, *o_uu;
-    int n, m;
-    __device__ __forceinline__ double load(long mat, int i, int j) const {
-        const double* vx = v_x + mat * n;
-        const double* p;
-        long st;
-        if (i < n && j < n) {
-            p = f_xx + mat * (long)n * n * n + (long)i * n + j;
-            st = (long)n * n;
-        } else if (i >= n && j >= n) {
-            p = f_uu + mat * (long)n * m * m + (long)(i - n) * m + (j - n);
-            st = (long)m * m;
-        } else {
-            const int u = (i >= n) ? i - n : j - n, x = (i >= n) ? j : i;   // f_ux[l][u][x], also under the transposed block
-            p = f_ux + mat * (long)n * m * n + (long)u * n + x;
-            st = (long)m * n;
-        }
-        double acc = 0.0;
-        for (int l = 0; l < n; ++l) acc = __builtin_fma(vx[l], p[l * st], acc);
-        return acc;
-    }
-    __device__ __forceinline__ void store(long mat, int i, int j, double v) const {
-        if (i < n) {
-            if (j < n) o_xx[(mat * n + i) * n + j] = v;
-        } else {
-            if (j < n)
-                o_ux[(mat * m + (i - n)) * n + j] = v;
-            else
-                o_uu[(mat * m + (i - n)) * m + (j - n)] = v;
-        }
-    }
-};
 
 #ifndef ZM_PSD_JACOBI
 // one wave per matrix: the k x k matrix sits zero-padded in one 16 x 16 MFMA tile (lane (g, c) holds rows 4r+g of column c) and
@@ -133,14 +70,18 @@ __global__ __launch_bounds__(64) void psd_project_kernel(const Mat M, const int 
 
 #endif
 
+// psd_tiled.hip: the same projection on NT x NT tiles for 16 < k <= 64
+int psd_project_tiled_plain(double* A, int64_t count, int k, double eps, hipStream_t st);
+int psd_project_tiled_cost(double* c_xx, double* c_ux, double* c_uu, int64_t count, int n, int m, double eps, hipStream_t st);
+
 }  // namespace zm
 
 extern "C" int zm_psd_project_f64(double* A, int64_t count, int k, double eps, void* stream) {
     if (count == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     if (!A) return zm::set_error(ZM_EINVAL, "zm_psd_project_f64: null pointer");
     if (count < 0 || k < 1) return zm::set_error(ZM_EINVAL, "zm_psd_project_f64: bad size");
-    if (k > zm::PK) return zm::set_error(ZM_EUNSUPPORTED, "zm_psd_project_f64: k=%d > 16", k);
-    if (count == 0) return ZM_OK;
+    if (k > 64) return zm::set_error(ZM_EUNSUPPORTED, "zm_psd_project_f64: k=%d > 64", k);
+    if (k > zm::PK) return zm::psd_project_tiled_plain(A, count, k, eps, (hipStream_t)stream);
     hipLaunchKernelGGL((zm::psd_project_kernel<zm::PlainMat>), dim3((unsigned)count), dim3(64), 0, (hipStream_t)stream,
                        zm::PlainMat{A, k}, k, eps, (long)count);
     ZM_HIP_CHECK(hipGetLastError());
@@ -152,8 +93,8 @@ extern "C" int zm_condition_cost_f64(double* c_xx, double* c_ux, double* c_uu, i
     if (count == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     if (!c_xx || !c_ux || !c_uu) return zm::set_error(ZM_EINVAL, "zm_condition_cost_f64: null pointer");
     if (count < 0 || n < 1 || m < 1) return zm::set_error(ZM_EINVAL, "zm_condition_cost_f64: bad size");
-    if (n + m > zm::PK) return zm::set_error(ZM_EUNSUPPORTED, "zm_condition_cost_f64: n+m=%d > 16", n + m);
-    if (count == 0) return ZM_OK;
+    if (n + m > 64) return zm::set_error(ZM_EUNSUPPORTED, "zm_condition_cost_f64: n+m=%d > 64", n + m);
+    if (n + m > zm::PK) return zm::psd_project_tiled_cost(c_xx, c_ux, c_uu, count, n, m, eps, (hipStream_t)stream);
     hipLaunchKernelGGL((zm::psd_project_kernel<zm::StackedCost>), dim3((unsigned)count), dim3(64), 0, (hipStream_t)stream,
                        zm::StackedCost{c_xx, c_ux, c_uu, n, m}, n + m, eps, (long)count);
     ZM_HIP_CHECK(hipGetLastError());

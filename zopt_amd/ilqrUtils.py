@@ -254,7 +254,7 @@ def forwardPass2(x0, dynFun, costFun, policy, trajPrev):
 
 def ensurePositiveDefinite(a, eps=1e-3):
     """`w, v = eigh(a); (v * max(w, eps)) @ v.T` (reference ilqrUtils.py:217-219; eigh symmetrises its input).
-    `a` is (..., k, k) with k <= 16; returns a new array."""
+    `a` is (..., k, k) with k <= 64 (one MFMA tile up to 16, NT x NT tiles beyond: psd_tiled.hip); returns a new array."""
     shp = _shape(a)
     if len(shp) < 2 or shp[-1] != shp[-2]:
         raise ValueError("a must be (..., k, k)")
