@@ -248,7 +248,9 @@ int zm_ddp_backward_f64(const double* f_x, const double* f_u, const double* f_xx
  * trajectory start for T > 1:   v' = (c + v) - 1/2 l^T Q_uu l,  v_x' = Q_x - L^T Q_uu l,  v_xx' = Q_xx - L^T Q_uu L   (:170).
  * in : as zm_ilqr_backward_f64, plus c (batch,T) or NULL and vf (batch) or NULL (the scalar terms);
  *      f_xx, f_ux, f_uu all NULL: iLQR step; all given: DDP step (PD-projected second-order dynamics terms)
- * out: l, L as before;  v_out (batch), vx_out (batch,n), vxx_out (batch,n,n), each may be NULL */
+ * out: l, L as before;  v_out (batch), vx_out (batch,n), vxx_out (batch,n,n), each may be NULL  * Shapes: n <= 12, m <= 4; the iLQR form (f_xx == f_ux == f_uu == NULL) also up to n <= 48, m <= 16 on the tile sweep (sweep_tiled_f64.hip;
+ * the three value outputs are then required).
+ */
 int zm_riccati_value_f64(const double* f_x, const double* f_u, const double* f_xx, const double* f_ux, const double* f_uu,
                          const double* c, const double* c_x, const double* c_u, const double* c_xx, const double* c_ux,
                          const double* c_uu, const double* vf, const double* vf_x, const double* vf_xx, double* l, double* L,

@@ -139,3 +139,51 @@ def test_quadcopter_expansions_random_points_horizons_and_wind(mods):
         scale = max(1.0, np.abs(F).max())
         for p, (a_, b_) in enumerate(ab):
             assert np.max(np.abs(Hn[:, :, p, :] - F[:, :, :, a_, b_])) <= 1e-12 * scale, (case, p)
+
+
+def test_large_state_sweeps_rollouts_and_projection(mods):
+    """The round-3 large-state kernels over random shapes: sweep_tiled_f64 (backwardPass_ilqr, bilinearAffineLqr; 12 < n <= 48 or
+    4 < m <= 16), rollout_wide (forwardPass2 of linear models up to n <= 64, m <= 16), psd_tiled (ensurePositiveDefinite up to 64)."""
+    lqr, ilqr, pt = mods
+    from zopt_amd import models
+    rng = np.random.default_rng(2027)
+    for case in range(24):
+        big_n = case % 2 == 0
+        n = int(rng.integers(13, 49)) if big_n else int(rng.integers(1, 13))
+        m = int(rng.integers(1, 17)) if big_n else int(rng.integers(5, 17))
+        T, b = int(rng.integers(1, 6)), int(rng.integers(1, 5))
+        dyn, cost, Vf = problems.random_ilqr_model(b, T, n, m, seed=5000 + case)
+        if case % 3 == 0:
+            c, c_x, c_u, c_xx, c_ux, c_uu = cost
+            cost = (c, c_x, c_u, c_xx + 0.1 * rng.standard_normal(c_xx.shape), c_ux, c_uu + 0.1 * rng.standard_normal(c_uu.shape))
+        pol = ilqr.backwardPass_ilqr(dyn, cost, Vf)
+        for i in range(b):
+            ref = zo.backwardPass_ilqr(zo.AffineDynamics(*(x[i] for x in dyn)), zo.QuadraticCostFunction(*(x[i] for x in cost)),
+                                       zo.QuadraticValueFunction(*(x[i] for x in Vf)))
+            assert _rel(pol.L[i], ref.L) <= 1e-10 and _rel(pol.l[i], ref.l) <= 1e-10, ("ilqr", case, n, m, T, b)
+        A, B, Q, R = problems.random_time_varying(b, T, n, m, seed=6000 + case)
+        d, H = 0.5 * rng.standard_normal((b, T, n)), 0.2 * rng.standard_normal((b, T, m, n))
+        q, r, q0 = rng.standard_normal((b, T, n)), rng.standard_normal((b, T, m)), rng.standard_normal((b, T))
+        L, l = lqr.bilinearAffineLqr(A, B, d, Q, R, H, q, r, q0, T)
+        Lr, lr = zo.bilinearAffineLqr(A, B, d, Q, R, H, q, r, q0, T)
+        assert _rel(L, Lr) <= 1e-10 and _rel(l, lr) <= 1e-10, ("affine", case, n, m, T, b)
+    for case in range(12):
+        n, m = int(rng.integers(13, 65)), int(rng.integers(1, 17))
+        N, b = int(rng.integers(1, 9)), int(rng.integers(1, 4))
+        model = models.LinearModel(rng.standard_normal((n, n)) * (1.0 / np.sqrt(n)), rng.standard_normal((n, m)))
+        Mq = rng.standard_normal((n, n))
+        cost = models.QuadraticCost(Mq @ Mq.T / n + np.eye(n), np.eye(m) + 0.1 * rng.standard_normal((m, m)), 10 * np.eye(n))
+        x0, l = rng.standard_normal((b, n)), 2.0 * rng.standard_normal((b, N, m)) * rng.uniform(0.05, 3.0, (b, 1, 1))
+        L = 0.2 * rng.standard_normal((b, N, m, n)) / np.sqrt(n)
+        xp, up = rng.standard_normal((b, N + 1, n)), 0.3 * rng.standard_normal((b, N, m))
+        traj, J = ilqr.forwardPass2(x0, model, cost, pt.AffinePolicy(l, L), pt.Trajectory(xp, up))
+        for i in range(b):
+            rt, rJ = zo.forwardPass2(x0[i], model, cost.runningCost, cost.terminalCost, zo.AffinePolicy(l[i], L[i]), zo.Trajectory(xp[i], up[i]))
+            assert abs(J[i] - rJ) <= 1e-10 * abs(rJ) and _rel(traj.uTraj[i], rt.uTraj) <= 1e-9, ("rollout", case, n, m, N, b)
+    for case in range(12):
+        k = int(rng.integers(17, 65))
+        M = rng.standard_normal((3, k, k))
+        A = M + np.swapaxes(M, -1, -2)
+        A[1] *= 1e-3                                            # a spectrum around the clamp
+        out, ref = ilqr.ensurePositiveDefinite(A), zo.ensurePositiveDefinite(A)
+        assert np.max(np.abs(out - ref)) <= 2e-11 * max(1.0, np.max(np.abs(ref))), ("psd", case, k)

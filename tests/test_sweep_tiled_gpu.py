@@ -106,3 +106,21 @@ def test_shapes_beyond_the_tile_kernels_are_refused(mods):
         lqr.bilinearAffineLqr(*_affine_problem(1, 2, 49, 4, 1, False), 2)
     with pytest.raises(ValueError):
         ilqr.backwardPass_ilqr(*problems.random_ilqr_model(1, 2, 16, 17, seed=1))
+
+
+@pytest.mark.parametrize("n,m,batch", [(16, 4, 3), (20, 6, 2), (33, 9, 2), (48, 16, 2)])
+def test_riccatiStep_ilqr_large_states_returns_the_value_function(mods, n, m, batch):
+    """`riccatiStep_ilqr` (reference ilqrUtils.py:153-173) beyond the one-tile shapes: the new value function (v, v_x, v_xx) AND the
+    policy of one step, nonsymmetric Hessians included."""
+    from zopt_amd import pytrees as pt
+    ilqr = mods[0]
+    dyn, cost, Vf = _nonsym_model(batch, 1, n, m, seed=77 + n)
+    sq = lambda t: tuple(x[:, 0] if x.ndim > 1 and x.shape[1] == 1 else x for x in t)   # one time step per item: drop the T = 1 axis
+    dyn1, cost1 = sq(dyn), sq(cost)
+    val, pol = ilqr.riccatiStep_ilqr(pt.AffineDynamics(*dyn1), pt.QuadraticCostFunction(*cost1), pt.QuadraticValueFunction(*Vf))
+    for b in range(batch):
+        rv, rp = zo.riccatiStep_ilqr(zo.AffineDynamics(*(x[b] for x in dyn1)), zo.QuadraticCostFunction(*(x[b] for x in cost1)),
+                                     zo.QuadraticValueFunction(*(x[b] for x in Vf)))
+        assert _rel(pol.L[b], rp.L) <= RTOL and _rel(pol.l[b], rp.l) <= RTOL
+        assert val.v[b] == pytest.approx(rv.v, rel=1e-10, abs=1e-12)
+        assert _rel(val.v_x[b], rv.v_x) <= RTOL and _rel(val.v_xx[b], rv.v_xx) <= RTOL

@@ -981,7 +981,8 @@ namespace zm {
 int sweep_tiled_f64_dispatch(int mode, const double* f_x, const double* f_u, const double* c_x, const double* c_u, const double* c_xx,
                              const double* c_ux, const double* c_uu, const double* vf_x, const double* vf_xx, const double* dvec,
                              long svx, long svxx, const int* active, int shared_hessian, double* l, double* L, int64_t batch, int T,
-                             int n, int m, hipStream_t st, const int* list, long count);
+                             int n, int m, hipStream_t st, const int* list, long count, const double* cs = nullptr,
+                             const double* vf = nullptr, double* v_out = nullptr, double* vx_out = nullptr, double* vxx_out = nullptr);
 }  // namespace zm
 
 // tiled: the entry point also has the large-state tile kernel (n <= 48, m <= 16) behind it
@@ -1129,8 +1130,13 @@ extern "C" int zm_riccati_value_f64(const double* f_x, const double* f_u, const 
     const bool ddp = f_xx || f_ux || f_uu;
     if (ddp && (!f_xx || (!f_ux != !f_uu)))
         return zm::set_error(ZM_EINVAL, "zm_riccati_value_f64: f_xx goes with f_ux and f_uu (the latter two may be NULL together: zero)");
-    const int rc = zm_check_sweep_args("zm_riccati_value_f64", batch, T, n, m);
+    const int rc = zm_check_sweep_args("zm_riccati_value_f64", batch, T, n, m, !ddp);
     if (rc) return rc;
+    if (!ddp && (n > 12 || m > 4)) {   // large states: the tile sweep with its value-function outputs (sweep_tiled_f64.hip)
+        if (!v_out || !vx_out || !vxx_out) return zm::set_error(ZM_EINVAL, "zm_riccati_value_f64: the value outputs are required at n > 12 or m > 4");
+        return zm::sweep_tiled_f64_dispatch(0, f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, (long)n, (long)n * n, nullptr, 0,
+                                            l, L, batch, T, n, m, (hipStream_t)stream, nullptr, 0, c, vf, v_out, vx_out, vxx_out);
+    }
     const zm::ValueIO v{c, vf, v_out, vx_out, vxx_out};
     if (ddp)
         return zm::launch_ilqr<2>(f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, (long)n, (long)n * n, nullptr, 0, l,

@@ -42,6 +42,10 @@ struct SweepTiledArgs {
     long batch;
     int T, n, m;
     TrajListT tl;
+    // MODE 0, optional: the value function riccatiStep_ilqr returns (ilqrUtils.py:170): scalar stage costs c (batch,T) and terminal v
+    // (batch) in; v, v_x (batch,n), v_xx (batch,n,n) at the start of the horizon out (all five NULL: policy only)
+    const double *cs, *vf;
+    double *v_out, *vx_out, *vxx_out;
 };
 
 template <int NT, int MODE>
@@ -87,6 +91,7 @@ __global__ __launch_bounds__(64) void sweep_tiled_f64(const SweepTiledArgs a) {
         if (lane < NP) vecs[0][lane] = lane < n ? vx[lane] : 0.0;
     }
     t_lds_sync();
+    double vs = (MODE == 0 && a.v_out && a.vf) ? a.vf[traj] : 0.0;   // scalar part of the value function (wave-uniform)
 
     for (int k = T - 1; k >= 0; --k) {
         // ---- operands of the step: F = [f_x | f_u] and the stacked cost Hessian as the accumulator init of G
@@ -337,6 +342,12 @@ __global__ __launch_bounds__(64) void sweep_tiled_f64(const SweepTiledArgs a) {
             vnew = qx;        // v_x' = Q_x - Xs^T (Q_uu xs)  (= Q_x - L^T Q_uu l)
 #pragma unroll
             for (int u_ = 0; u_ < 16; ++u_) vnew = __builtin_fma(-x[u_], TR::readlane(w, u_), vnew);
+            if (a.v_out) {    // v' = (c + v) - l^T Q_uu l / 2,  l^T Q_uu l = xs^T (Q_uu xs)                       (ilqrUtils.py:170)
+                double lql = 0.0;
+#pragma unroll
+                for (int u_ = 0; u_ < 16; ++u_) lql = __builtin_fma(TR::readlane(x[u_], NP), TR::readlane(w, u_), lql);
+                vs = ((a.cs ? a.cs[traj * T + k] : 0.0) + vs) - 0.5 * lql;
+            }
         } else {
             vnew = qx;        // v' = q + A^T (v + V d) - Sux^T l
 #pragma unroll
@@ -344,6 +355,23 @@ __global__ __launch_bounds__(64) void sweep_tiled_f64(const SweepTiledArgs a) {
         }
         if (lane < NP) vecs[0][lane] = vnew;
         t_lds_sync();
+    }
+    if constexpr (MODE == 0) {
+        if (a.v_out) {   // value function at the start of the horizon
+            if (lane == 0) a.v_out[traj] = vs;
+            if (a.vx_out && lane < n) a.vx_out[traj * n + lane] = vecs[0][lane];
+            if (a.vxx_out) {
+#pragma unroll
+                for (int K = 0; K < NT; ++K)
+#pragma unroll
+                    for (int J = 0; J < NT; ++J)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = 16 * K + TR::row(g, r), j = 16 * J + c;
+                            if (i < n && j < n) a.vxx_out[traj * nn + (long)i * n + j] = V[K][J][r];
+                        }
+            }
+        }
     }
 }
 
@@ -363,11 +391,12 @@ static int launch_sweep_tiled(int mode, const SweepTiledArgs& a, long nslot, hip
 int sweep_tiled_f64_dispatch(int mode, const double* f_x, const double* f_u, const double* c_x, const double* c_u, const double* c_xx,
                              const double* c_ux, const double* c_uu, const double* vf_x, const double* vf_xx, const double* dvec,
                              long svx, long svxx, const int* active, int shared_hessian, double* l, double* L, int64_t batch, int T,
-                             int n, int m, hipStream_t st, const int* list, long count) {
+                             int n, int m, hipStream_t st, const int* list, long count, const double* cs, const double* vf,
+                             double* v_out, double* vx_out, double* vxx_out) {
     if (n < 1 || m < 1 || n > 48 || m > 16 || (mode != 0 && mode != 1)) return ZM_EUNSUPPORTED;
     if (mode == 1 && !dvec) return set_error(ZM_EINVAL, "sweep_tiled_f64: the affine sweep needs d");
     const SweepTiledArgs a{f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, dvec, svx, svxx, active, shared_hessian, l, L,
-                           (long)batch, T, n, m, TrajListT{list, count}};
+                           (long)batch, T, n, m, TrajListT{list, count}, cs, vf, v_out, vx_out, vxx_out};
     const long nslot = list ? count : (long)batch;
     if (nslot == 0) return ZM_OK;
     if (n <= 16) return launch_sweep_tiled<1>(mode, a, nslot, st);
