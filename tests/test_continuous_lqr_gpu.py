@@ -189,6 +189,28 @@ def test_riccati_ode_time_varying_batch(lqr):
     assert np.all(K.info > 0)
 
 
+def test_riccati_ode_smooth_time_varying_coefficients_are_refined(lqr):
+    """Coefficients that are NOT piecewise linear in t (the reference evaluates the callables inside the integrator's right-hand side,
+    lqrUtils.py:39-52, 88-97): the host-side sampling is refined until the value function stops changing, and the result agrees with
+    the oracle's integration of the exact callables to the integrator's tolerance -- where the unrefined default grid does not."""
+    rng = np.random.default_rng(8)
+    n, m, T, N = 5, 2, 3.0, 7
+    A0, A1 = 0.4 * rng.standard_normal((2, n, n))
+    B0 = rng.standard_normal((n, m))
+    At = lambda t: A0 * np.cos(2.5 * t) + A1 * np.sin(1.7 * t) ** 2
+    Bt = lambda t: B0 * (1.0 + 0.5 * np.sin(3.0 * t))
+    Qt = lambda t: np.eye(n) * np.exp(0.4 * t)
+    Rt = lambda t: np.eye(m) / (1.0 + 0.3 * t * t)
+    Qf = 2.0 * np.eye(n)
+    Kr, _, Vr = zo.finiteHorizonLqr(At, Bt, Qt, Rt, Qf, T, N=N)
+    K = lqr.finiteHorizonLqr(At, Bt, Qt, Rt, Qf, T, N=N)
+    assert K.n_samples > 8 * (N - 1) + 1 and K.coef_change <= 1e-6 * np.max(np.abs(K.V))
+    err = _rel(K.V, Vr)
+    assert err <= 2e-6 and _rel(K(0.8), Kr(0.8)) <= 5e-5            # (K(t) interpolates V linearly between the N output times, as the reference does)
+    K0 = lqr.finiteHorizonLqr(At, Bt, Qt, Rt, Qf, T, N=N, n_samples=8 * (N - 1) + 1)     # refinement off: the round-2 behaviour
+    assert _rel(K0.V, Vr) > 10 * err
+
+
 def test_riccati_ode_edge_cases(lqr):
     import torch
     c = lambda t: I2

@@ -272,7 +272,8 @@ class _GainSchedule:
         return np.asarray(Ri) @ np.swapaxes(np.asarray(B), -1, -2) @ V
 
 
-def finiteHorizonLqr(A, B, Q, R_inv, Qf, T, N=50, n_samples=None, rtol=1.4e-8, atol=1.4e-8, max_steps=100000):
+def finiteHorizonLqr(A, B, Q, R_inv, Qf, T, N=50, n_samples=None, rtol=1.4e-8, atol=1.4e-8, max_steps=100000, coef_rtol=1e-6,
+                     max_refinements=7):
     """Continuous-time finite-horizon LQR gains by integrating the LQR Hamilton-Jacobi-Bellman (Riccati) equation
     (reference lqrUtils.py:39-98).
 
@@ -281,9 +282,14 @@ def finiteHorizonLqr(A, B, Q, R_inv, Qf, T, N=50, n_samples=None, rtol=1.4e-8, a
     ```
     Here: `dV/dt = -Q + V B R_inv B^T V - V A - A^T V` backwards from `V(T) = Qf` on the GPU, one wave per design, with the
     adaptive Dormand-Prince 5(4) pair and tolerances of `jax.experimental.ode.odeint` (the reference's integrator), stepping
-    exactly onto the output times `linspace(0, T, N)`.  The coefficient callables are host Python: they are sampled at
-    `linspace(0, T, n_samples)` (default `8 (N - 1) + 1`; a single sample when all samples agree) and the kernel interpolates
-    linearly in between -- exact for time-invariant (the reference's demos and tests) and piecewise-linear coefficients.
+    exactly onto the output times `linspace(0, T, N)`.  The coefficient callables are host Python (the reference evaluates them
+    inside the integrator's right-hand side): they are sampled at `linspace(0, T, n_samples)` and the kernel interpolates linearly
+    in between -- exact for time-invariant coefficients (the reference's demos and tests; a single sample then) and for
+    piecewise-linear ones.  For other time-varying coefficients the sampling is REFINED until it no longer matters: starting
+    from `8 (N - 1) + 1` samples the spacing is halved (interpolation error / 4 each time) until the value function changes by
+    less than `coef_rtol * max|V|` between two refinements (default 1e-6: the level at which two runs of the adaptive integrator
+    differ anyway), at most `max_refinements` times (`K.n_samples` / `K.coef_change`
+    report what was reached).  An explicit `n_samples` switches the refinement off.
 
     Arguments
     ---------
@@ -299,45 +305,65 @@ def finiteHorizonLqr(A, B, Q, R_inv, Qf, T, N=50, n_samples=None, rtol=1.4e-8, a
     N = int(N)
     if not (T > 0.0) or N < 1:
         _shape_error("T must be > 0 and N >= 1")
-    ns = int(n_samples) if n_samples is not None else 8 * (N - 1) + 1
-    if ns < 1:
+    ns0 = int(n_samples) if n_samples is not None else 8 * (N - 1) + 1
+    if ns0 < 1:
         _shape_error("n_samples must be >= 1")
     dt = torch.float64
-    ts = np.linspace(0.0, T, ns)
     dev = arr.to_device(Qf, dt).device
-
-    def sample(f):
-        vals = [arr.to_device(f(float(tk)), dt, dev) for tk in ts]
-        if all(v.shape == vals[0].shape and bool((v == vals[0]).all()) for v in vals[1:]):
-            vals = vals[:1]           # time-invariant
-        return vals
-
-    sA, sB, sQ, sRi = sample(A), sample(B), sample(Q), sample(R_inv)
-    cnt = max(len(sA), len(sB), len(sQ), len(sRi))
-    stack = lambda v: torch.stack(v if len(v) == cnt else v * cnt, dim=-3).contiguous()
-    dA, dB, dQ, dRi = stack(sA), stack(sB), stack(sQ), stack(sRi)
     dQf = arr.to_device(Qf, dt, dev).contiguous()
-    if dB.dim() < 3:
-        _shape_error("B(t) must have shape (..., n, m)")
-    n, m = dB.shape[-2:]
-    lead = tuple(dB.shape[:-3])
-    for name, X, tail in (("A(t)", dA, (cnt, n, n)), ("Q(t)", dQ, (cnt, n, n)), ("R_inv(t)", dRi, (cnt, m, m))):
-        if tuple(X.shape) != lead + tail:
-            _shape_error(f"{name} has shape {tuple(X.shape[:-3]) + tuple(X.shape[-2:])}, expected {lead + tail[1:]}")
-    if tuple(dQf.shape) != lead + (n, n):
-        _shape_error(f"Qf has shape {tuple(dQf.shape)}, expected {lead + (n, n)}")
-    batch = 1
-    for d in lead:
-        batch *= int(d)
-    dV = torch.empty(lead + (N, n, n), dtype=dt, device=dev)
-    info = torch.ones(lead, dtype=torch.int32, device=dev)
-    rc = 0 if batch == 0 else _lib.lib().zm_riccati_ode_f64(dA.data_ptr(), dB.data_ptr(), dRi.data_ptr(), dQ.data_ptr(),
-                                                            dQf.data_ptr(), dV.data_ptr(), info.data_ptr(), batch, n, m, cnt, N,
-                                                            T, float(rtol), float(atol), int(max_steps),
-                                                            ctypes.c_void_p(arr.stream_ptr(dQf)))
-    _lib.check(rc, "finiteHorizonLqr")
+
+    def integrate(ns):
+        ts = np.linspace(0.0, T, ns)
+
+        def sample(f):
+            vals = [arr.to_device(f(float(tk)), dt, dev) for tk in ts]
+            if all(v.shape == vals[0].shape and bool((v == vals[0]).all()) for v in vals[1:]):
+                vals = vals[:1]           # time-invariant
+            return vals
+
+        sA, sB, sQ, sRi = sample(A), sample(B), sample(Q), sample(R_inv)
+        cnt = max(len(sA), len(sB), len(sQ), len(sRi))
+        stack = lambda v: torch.stack(v if len(v) == cnt else v * cnt, dim=-3).contiguous()
+        dA, dB, dQ, dRi = stack(sA), stack(sB), stack(sQ), stack(sRi)
+        if dB.dim() < 3:
+            _shape_error("B(t) must have shape (..., n, m)")
+        n, m = dB.shape[-2:]
+        lead = tuple(dB.shape[:-3])
+        for name, X, tail in (("A(t)", dA, (cnt, n, n)), ("Q(t)", dQ, (cnt, n, n)), ("R_inv(t)", dRi, (cnt, m, m))):
+            if tuple(X.shape) != lead + tail:
+                _shape_error(f"{name} has shape {tuple(X.shape[:-3]) + tuple(X.shape[-2:])}, expected {lead + tail[1:]}")
+        if tuple(dQf.shape) != lead + (n, n):
+            _shape_error(f"Qf has shape {tuple(dQf.shape)}, expected {lead + (n, n)}")
+        batch = 1
+        for d in lead:
+            batch *= int(d)
+        dV = torch.empty(lead + (N, n, n), dtype=dt, device=dev)
+        info = torch.ones(lead, dtype=torch.int32, device=dev)
+        rc = 0 if batch == 0 else _lib.lib().zm_riccati_ode_f64(dA.data_ptr(), dB.data_ptr(), dRi.data_ptr(), dQ.data_ptr(),
+                                                                dQf.data_ptr(), dV.data_ptr(), info.data_ptr(), batch, n, m, cnt, N,
+                                                                T, float(rtol), float(atol), int(max_steps),
+                                                                ctypes.c_void_p(arr.stream_ptr(dQf)))
+        _lib.check(rc, "finiteHorizonLqr")
+        return dV, info, cnt
+
+    ns = ns0
+    dV, info, cnt = integrate(ns)
+    change = 0.0
+    if n_samples is None and cnt > 1 and dV.numel():
+        # time-varying coefficients: halve the sample spacing until the linear interpolation no longer shows in V
+        for _ in range(int(max_refinements)):
+            ns = 2 * (ns - 1) + 1
+            dV2, info2, _ = integrate(ns)
+            fin = torch.isfinite(dV2) & torch.isfinite(dV)
+            scale = float(dV2[fin].abs().max()) if bool(fin.any()) else 0.0
+            change = float((dV2 - dV)[fin].abs().max()) if bool(fin.any()) else 0.0
+            dV, info = dV2, info2
+            if change <= float(coef_rtol) * max(scale, 1e-300):
+                break
     K = _GainSchedule(np.linspace(0.0, T, N), arr.result_like(dV, Qf), B, R_inv, T)
     K.info = arr.result_like(info, Qf)
+    K.n_samples = ns if cnt > 1 else 1
+    K.coef_change = change
     return K
 
 
