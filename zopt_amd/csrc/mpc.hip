@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const double* __restrict_
     bool done = !live || status != 0;
     for (int gi = 0; gi < g.max_iter; ++gi) {  // gi is wave-uniform
         if (__all(done)) break;
-        const bool chk = ((gi + 1) % 25) == 0;  // infeasibility certificate on this iteration
+        const bool chk = ((gi + 1) % ZM_MPC_CHK) == 0;  // infeasibility certificate on this iteration
         // ---- backward affine sweep.  Costate of x_{k+1}: p = -rho z(x_{k+1}) + (A^T p - K^T Qu)_{k+1};
         //      Qu = -rho z(u_k) + B^T p;  kf_k = Suu_k^-1 Qu.  Stage k touches only block k of (y, lam) (its states are the copy
         //      of x_{k+1}), and block k-1 is fetched while stage k computes: no load is predicated, no store is conditional

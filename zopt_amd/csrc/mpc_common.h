@@ -2,6 +2,12 @@
 #pragma once
 #include "zm_common.h"
 
+// Every ZM_MPC_CHK-th ADMM iteration checks the primal-infeasibility certificate and lets the adaptive penalty move (OSQP's
+// `check_termination` / `adaptive_rho_interval`, both tunables of the solver, not of the problem).
+#ifndef ZM_MPC_CHK
+#define ZM_MPC_CHK 25
+#endif
+
 namespace zm {
 
 struct MpcArgs {

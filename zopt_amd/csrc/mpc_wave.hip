@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
     bool done = !live || status != 0;              // group-uniform
     for (int gi = 0; gi < g.max_iter; ++gi) {
         if (__all(done)) break;
-        const bool chk = ((gi + 1) % 25) == 0;
+        const bool chk = ((gi + 1) % ZM_MPC_CHK) == 0;
         // ---- backward affine sweep.  The table slices come from L2 (~500+ cycles) and a stage is shorter than that, so they are
         //      fetched THREE stages ahead into a rotating set of registers (the loop is unrolled by three: no copies).
         double pp = 0.0;   // (A^T p - K^T Qu) of the stage above
