@@ -124,3 +124,74 @@ def test_riccatiStep_ilqr_large_states_returns_the_value_function(mods, n, m, ba
         assert _rel(pol.L[b], rp.L) <= RTOL and _rel(pol.l[b], rp.l) <= RTOL
         assert val.v[b] == pytest.approx(rv.v, rel=1e-10, abs=1e-12)
         assert _rel(val.v_x[b], rv.v_x) <= RTOL and _rel(val.v_xx[b], rv.v_xx) <= RTOL
+
+
+def _ddp_model(batch, T, n, m, seed):
+    dyn, cost, Vf = problems.random_ilqr_model(batch, T, n, m, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    sym = lambda X: 0.5 * (X + np.swapaxes(X, -1, -2))
+    f_xx = 0.2 * sym(rng.standard_normal((batch, T, n, n, n))) / np.sqrt(n)
+    f_ux = 0.2 * rng.standard_normal((batch, T, n, m, n)) / np.sqrt(n)
+    f_uu = 0.2 * sym(rng.standard_normal((batch, T, n, m, m))) / np.sqrt(n)
+    return dyn + (f_xx, f_ux, f_uu), cost, Vf
+
+
+@pytest.mark.parametrize("n,m,T,batch", [(16, 4, 5, 3), (13, 2, 4, 2), (20, 6, 4, 2), (33, 9, 3, 2), (48, 16, 2, 2), (8, 6, 4, 2)])
+def test_backwardPass_ddp_large_states(mods, n, m, T, batch):
+    """`backwardPass_ddp` (reference ilqrUtils.py:184-214, 237-251) beyond the one-tile DDP sweep: per time step a torch contraction
+    `sum_i v_x[i] d2f_i`, the HIP PD projection of the stacked (n+m)^2 matrix (one tile up to 16, multi-tile beyond) and the HIP tile sweep
+    for one step with the projected blocks added to the cost Hessians; against the oracle (eigh) at 1e-9."""
+    ilqr = mods[0]
+    dyn, cost, Vf = _ddp_model(batch, T, n, m, seed=11 * n + m)
+    pol = ilqr.backwardPass_ddp(dyn, cost, Vf)
+    for b in range(batch):
+        ref = zo.backwardPass_ddp(zo.QuadraticDynamics(*(x[b] for x in dyn)), zo.QuadraticCostFunction(*(x[b] for x in cost)),
+                                  zo.QuadraticValueFunction(*(x[b] for x in Vf)))
+        assert _rel(pol.L[b], ref.L) <= 1e-9 and _rel(pol.l[b], ref.l) <= 1e-9
+
+
+def test_riccatiStep_ddp_and_conditionQuadraticDynamics_large_states(mods):
+    from zopt_amd import pytrees as pt
+    ilqr = mods[0]
+    n, m, batch = 20, 6, 3
+    dyn, cost, Vf = _ddp_model(batch, 1, n, m, seed=5)
+    sq = lambda t: tuple(x[:, 0] for x in t)
+    dyn1, cost1 = sq(dyn), sq(cost)
+    val, pol = ilqr.riccatiStep_ddp(pt.QuadraticDynamics(*dyn1), pt.QuadraticCostFunction(*cost1), pt.QuadraticValueFunction(*Vf))
+    blocks = ilqr.conditionQuadraticDynamics(pt.QuadraticDynamics(*dyn1), Vf[1])
+    for b in range(batch):
+        rv, rp = zo.riccatiStep_ddp(zo.QuadraticDynamics(*(x[b] for x in dyn1)), zo.QuadraticCostFunction(*(x[b] for x in cost1)),
+                                    zo.QuadraticValueFunction(*(x[b] for x in Vf)))
+        assert _rel(pol.L[b], rp.L) <= 1e-9 and _rel(pol.l[b], rp.l) <= 1e-9
+        assert val.v[b] == pytest.approx(rv.v, rel=1e-9, abs=1e-11) and _rel(val.v_x[b], rv.v_x) <= 1e-9 and _rel(val.v_xx[b], rv.v_xx) <= 1e-9
+        rb = zo.conditionQuadraticDynamics(zo.QuadraticDynamics(*(x[b] for x in dyn1)), Vf[1][b])
+        for got, ref in zip(blocks, rb):
+            assert _rel(got[b], ref) <= 2e-11
+    with pytest.raises(ValueError):
+        ilqr.backwardPass_ddp(*_ddp_model(1, 2, 49, 2, seed=1))
+
+
+def test_generic_ddp_beyond_the_one_tile_shapes(mods):
+    """`differentialDynamicProgramming` with torch callables at n = 14, m = 5: expansions incl. second derivatives by torch.func, the
+    backward pass through the per-step large-shape path; against the oracle's DDP loop."""
+    import torch
+    ilqr = mods[0]
+    n, m, N = 14, 5, 8
+    rng = np.random.default_rng(4)
+    K = 0.15 * rng.standard_normal((n, n)) / np.sqrt(n)
+    Bm = 0.3 * rng.standard_normal((n, m))
+    dt = 0.1
+    tK, tB = torch.as_tensor(K, device="cuda"), torch.as_tensor(Bm, device="cuda")
+    cK, cB = torch.as_tensor(K), torch.as_tensor(Bm)
+    f_np = lambda x, u: x + dt * (K @ x - 0.05 * x ** 3 + Bm @ u)
+    f_gpu = lambda x, u: x + dt * (tK @ x - 0.05 * x ** 3 + tB @ u)
+    f_cpu = lambda x, u: x + dt * (cK @ x - 0.05 * x ** 3 + cB @ u)          # the oracle differentiates a CPU torch restatement
+    Q, R, Qf = np.eye(n), 0.5 * np.eye(m), 5 * np.eye(n)
+    tQ, tR, tQf = (torch.as_tensor(M, device="cuda") for M in (Q, R, Qf))
+    x0 = rng.uniform(-1.5, 1.5, (2, n))
+    ug = np.zeros((2, N, m))
+    traj, L, J, conv = ilqr.differentialDynamicProgramming(f_gpu, lambda x, u: x @ tQ @ x + u @ tR @ u, lambda x: x @ tQf @ x, x0, ug)
+    for i in range(2):
+        rt, rL, rJ, rc = zo.differentialDynamicProgramming(f_np, f_cpu, Q, R, Qf, x0[i], ug[i])
+        assert bool(conv[i]) == rc and J[i] == pytest.approx(rJ, rel=1e-7)
+        assert _rel(traj.uTraj[i], rt.uTraj) <= 1e-5 and _rel(L[i], rL) <= 1e-4

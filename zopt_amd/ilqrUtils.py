@@ -94,6 +94,47 @@ def backwardPass_ilqr(dynamics, cost, Vf):
     return AffinePolicy(arr.result_like(dl, template), arr.result_like(dL, template))
 
 
+def _ddp_large(n, m):
+    """Shapes the one-tile DDP kernels (ilqr_backward.hip MODE 2, psd.hip's contracted-dynamics kernel) do not take."""
+    return n > 12 or m > 4
+
+
+def _project_vf_zz(v_x, f_xx, f_ux, f_uu, eps=1e-3):
+    """conditionQuadraticDynamics for LARGE shapes (reference ilqrUtils.py:237-251) on flat batches: `vf_.. = einsum('i,ijk', v_x, f_..)`
+    (a torch contraction on the GPU), the stacked `[[vf_xx, vf_ux^T],[vf_ux, vf_uu]]` PD-projected by the HIP kernel (zm_psd_project_f64:
+    multi-tile matrix-sign iteration beyond 16 x 16), blocks returned.  Arguments (b, n), (b, n, n, n), (b, n, m, n), (b, n, m, m)."""
+    n, m = f_ux.shape[-1], f_ux.shape[-2]
+    vf_xx = torch.einsum("bi,bijk->bjk", v_x, f_xx)
+    vf_ux = torch.einsum("bi,bijk->bjk", v_x, f_ux)
+    vf_uu = torch.einsum("bi,bijk->bjk", v_x, f_uu)
+    Z = torch.cat([torch.cat([vf_xx, vf_ux.transpose(-1, -2)], dim=-1), torch.cat([vf_ux, vf_uu], dim=-1)], dim=-2).contiguous()
+    if Z.shape[0]:
+        rc = _lib.lib().zm_psd_project_f64(Z.data_ptr(), Z.shape[0], n + m, float(eps), ctypes.c_void_p(arr.stream_ptr(Z)))
+        _lib.check(rc, "conditionQuadraticDynamics")
+    return Z[:, :n, :n], Z[:, n:, :n], Z[:, n:, n:]
+
+
+def _riccati_value_call(f_x, f_u, c, c_x, c_u, c_xx, c_ux, c_uu, v, v_x, v_xx):
+    """zm_riccati_value_f64 (iLQR form, one time step) on flat contiguous batches; returns (v', v_x', v_xx', l, L)."""
+    b, n, m = f_u.shape
+    dt, dev = f_x.dtype, f_x.device
+    dl, dL = torch.empty((b, m), dtype=dt, device=dev), torch.empty((b, m, n), dtype=dt, device=dev)
+    ov, ovx, ovxx = torch.empty(b, dtype=dt, device=dev), torch.empty((b, n), dtype=dt, device=dev), torch.empty((b, n, n), dtype=dt, device=dev)
+    ts = [t.contiguous() for t in (f_x, f_u, c, c_x, c_u, c_xx, c_ux, c_uu, v, v_x, v_xx)]
+    rc = _lib.lib().zm_riccati_value_f64(ts[0].data_ptr(), ts[1].data_ptr(), None, None, None, *[t.data_ptr() for t in ts[2:]],
+                                         dl.data_ptr(), dL.data_ptr(), ov.data_ptr(), ovx.data_ptr(), ovxx.data_ptr(), b, 1, n, m,
+                                         ctypes.c_void_p(arr.stream_ptr(f_x)))
+    _lib.check(rc, "riccatiStep")
+    return ov, ovx, ovxx, dl, dL
+
+
+def _ddp_step_large(f_x, f_u, f_xx, f_ux, f_uu, c, c_x, c_u, c_xx, c_ux, c_uu, v, v_x, v_xx):
+    """riccatiStep_ddp for large shapes (reference ilqrUtils.py:184-206): the iLQR step (HIP tile sweep, T = 1) with the cost Hessians
+    augmented by the PD-projected second-order terms -- Q_xx = c_xx + f_x^T v_xx f_x + vf_xx etc. (:196-198)."""
+    vf_xx, vf_ux, vf_uu = _project_vf_zz(v_x, f_xx, f_ux, f_uu)
+    return _riccati_value_call(f_x, f_u, c, c_x, c_u, c_xx + vf_xx, c_ux + vf_ux, c_uu + vf_uu, v, v_x, v_xx)
+
+
 def _riccati_step(dynamics, cost, value, ddp):
     """One backward step with the value function returned (zm_riccati_value_f64, T = 1)."""
     dyn = _fields(dynamics)
@@ -125,6 +166,15 @@ def _riccati_step(dynamics, cost, value, ddp):
     for d in lead:
         batch *= int(d)
     dev = df_x.device
+    if ddp and _ddp_large(n, m):
+        fl = lambda t, tail: t.reshape((batch,) + tail)
+        ov, ovx, ovxx, dl, dL = _ddp_step_large(fl(df_x, (n, n)), fl(df_u, (n, m)), fl(zk[0], (n, n, n)), fl(zk[1], (n, m, n)),
+                                                fl(zk[2], (n, m, m)), fl(dc, ()), fl(dc_x, (n,)), fl(dc_u, (m,)), fl(dc_xx, (n, n)),
+                                                fl(dc_ux, (m, n)), fl(dc_uu, (m, m)), fl(dv, ()), fl(dv_x, (n,)), fl(dv_xx, (n, n)))
+        outs = [arr.result_like(o.reshape(lead + tuple(o.shape[1:])), template) for o in (ov, ovx, ovxx, dl, dL)]
+        if not arr.is_torch(template) and len(lead) == 0:
+            outs[0] = float(outs[0])
+        return QuadraticValueFunction(*outs[:3]), AffinePolicy(*outs[3:])
     dl = torch.empty(lead + (m,), dtype=dt, device=dev)
     dL = torch.empty(lead + (m, n), dtype=dt, device=dev)
     ov = torch.empty(lead, dtype=dt, device=dev)
@@ -311,6 +361,10 @@ def conditionQuadraticDynamics(quadratic_dynamics, v_x):
     count = 1
     for d in lead:
         count *= int(d)
+    if n + m > 16:      # beyond the one-tile kernel: torch contraction + the multi-tile HIP projection
+        oxx, oux, ouu = _project_vf_zz(dvx.reshape(count, n), dxx.reshape(count, n, n, n), dux.reshape(count, n, m, n),
+                                       duu.reshape(count, n, m, m))
+        return tuple(arr.result_like(o.reshape(lead + tuple(o.shape[1:])).contiguous(), f_xx) for o in (oxx, oux, ouu))
     oxx = torch.empty(lead + (n, n), dtype=dt, device=dxx.device)
     oux = torch.empty(lead + (m, n), dtype=dt, device=dxx.device)
     ouu = torch.empty(lead + (m, m), dtype=dt, device=dxx.device)
@@ -367,6 +421,21 @@ def backwardPass_ddp(dynamics, cost, Vf):
         batch *= int(d)
     dl = torch.empty(lead + (N, m), dtype=dt, device=dev[0].device)
     dL = torch.empty(lead + (N, m, n), dtype=dt, device=dev[0].device)
+    if _ddp_large(n, m):
+        # Beyond the one-tile DDP sweep (n <= 12, m <= 4) the recursion runs step by step from the host: per step a torch contraction,
+        # the HIP PD projection of the stacked (n+m)^2 matrix and the HIP tile sweep for one step (three launches per time step:
+        # a coverage path for the shapes the generic-callable drivers take, not a fast one).
+        if n > 48 or m > 16:
+            raise ValueError(f"backwardPass_ddp: (n={n}, m={m}) not covered (need n <= 48, m <= 16)")
+        fx, fu, fxx, fux, fuu, cx, cu, cxx, cux, cuu, vx, vxx = (t.reshape((batch,) + tuple(t.shape[len(lead):])) for t in dev)
+        vv = torch.zeros(batch, dtype=dt, device=vx.device)
+        zc = torch.zeros(batch, dtype=dt, device=vx.device)
+        fl, fL = dl.reshape(batch, N, m), dL.reshape(batch, N, m, n)
+        for k in range(N - 1, -1, -1):
+            vv, vx, vxx, lk, Lk = _ddp_step_large(fx[:, k], fu[:, k], fxx[:, k].contiguous(), fux[:, k].contiguous(), fuu[:, k].contiguous(),
+                                                  zc, cx[:, k], cu[:, k], cxx[:, k], cux[:, k], cuu[:, k], vv, vx, vxx)
+            fl[:, k], fL[:, k] = lk, Lk
+        return AffinePolicy(arr.result_like(dl, f_x), arr.result_like(dL, f_x))
     rc = _lib.lib().zm_ddp_backward_f64(*[t.data_ptr() for t in dev], None, 0, dl.data_ptr(), dL.data_ptr(), batch, N, n, m,
                                         ctypes.c_void_p(arr.stream_ptr(dev[0])))
     _lib.check(rc, "backwardPass_ddp")
