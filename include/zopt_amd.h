@@ -74,7 +74,9 @@ int zm_lqr_backward_affine_f64(const double* A, const double* B, const double* d
 
 /* Batched discrete-time infinite-horizon LQR (DARE) by Riccati value iteration from V = Q on registers.
  * Replaces: zopt/lqrUtils.py:176-204 discreteInfiniteHorizonLqr (SciPy solve_discrete_are + one solve).
- * in : A (batch,n,n)  B (batch,n,m)  Q (batch,n,n)  R (batch,m,m)   [device]; n <= 12, m <= 4
+ * in : A (batch,n,n)  B (batch,n,m)  Q (batch,n,n)  R (batch,m,m)   [device]; n <= 64, m <= 16 (n <= 12, m <= 4: K1's step with the
+ *      operands in registers, stopping on max|V' - V| <= tol max|V'|; beyond: the fp64 tile kernel's Joseph-form step on time-invariant
+ *      operands, stopping on max|L_k - L_{k-1}| <= tol max|L_k|, P = the value after that step)
  *      tol: stop when max|V' - V| <= tol * max|V'| (or at the rounding floor); max_iter: iteration cap
  * out: L (batch,m,n) with u = -L x;  P (batch,n,n) or NULL: the value matrix;
  *      iters (batch) or NULL: +k = converged after k iterations (also when k == max_iter), -k = the cap ended the loop after k

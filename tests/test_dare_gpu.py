@@ -69,7 +69,7 @@ def test_torch_batch_axes_and_iteration_cap(lqr):
     with pytest.raises(np.linalg.LinAlgError):          # not stabilizable: unstable mode the input cannot reach
         lqr.discreteInfiniteHorizonLqr(np.diag([2.0, 0.5]), np.array([[0.0], [1.0]]), np.eye(2), np.eye(1), maxIter=2000)
     with pytest.raises(ValueError):
-        lqr.discreteInfiniteHorizonLqr(np.eye(13), np.ones((13, 2)), np.eye(13), np.eye(2))
+        lqr.discreteInfiniteHorizonLqr(np.eye(65), np.ones((65, 2)), np.eye(65), np.eye(2))
     # convergence EXACTLY on the last allowed iteration is convergence (the kernel reports it, the count alone cannot tell):
     # a design that needs k iterations is accepted with maxIter = k and refused with maxIter = k - 4 (the test runs every 4th)
     L1, _, k = lqr.discreteInfiniteHorizonLqr(A[:1], B[:1], Q[:1], R[:1], return_value=True)
@@ -80,3 +80,27 @@ def test_torch_batch_axes_and_iteration_cap(lqr):
     assert np.array_equal(lqr.discreteInfiniteHorizonLqr(A[:1], B[:1], Q[:1], R[:1], maxIter=k), L1)      # no LinAlgError
     with pytest.raises(np.linalg.LinAlgError):
         lqr.discreteInfiniteHorizonLqr(A[:1], B[:1], Q[:1], R[:1], maxIter=k - 4)
+
+
+@pytest.mark.parametrize("n,m,rho", [(16, 4, 0.95), (13, 5, 1.1), (24, 8, 0.9), (33, 7, 1.05), (48, 16, 0.95), (64, 16, 0.9), (57, 3, 1.02), (12, 6, 1.2)])
+def test_matches_scipy_dare_large_states(lqr, n, m, rho):
+    """`discreteInfiniteHorizonLqr` beyond the tile-16 shapes (12 < n <= 64 or 4 < m <= 16): the fp64 tile kernel's Joseph-form step
+    iterated on time-invariant operands until the gain stops changing; stable and unstable random systems against SciPy's
+    solve_discrete_are -- the library the reference itself calls (lqrUtils.py:202-203)."""
+    batch = 3
+    A, B, Q, R = problems.random_lti_systems(batch, n, m, seed=70 + n, rho=rho)
+    L, V, its = lqr.discreteInfiniteHorizonLqr(A, B, Q, R, return_value=True)
+    assert L.shape == (batch, m, n) and V.shape == (batch, n, n) and its.shape == (batch,)
+    for i in range(batch):
+        Lr, Vr = zo.discreteInfiniteHorizonLqr(A[i], B[i], Q[i], R[i])
+        assert np.max(np.abs(L[i] - Lr)) <= 1e-10 * max(np.max(np.abs(Lr)), 1.0), (i, its[i])
+        assert np.max(np.abs(V[i] - Vr)) <= 1e-9 * np.max(np.abs(Vr)), (i, its[i])
+        assert 1 <= its[i] < 200000
+    assert np.array_equal(lqr.discreteInfiniteHorizonLqr(A, B, Q, R), L)
+    with pytest.raises(np.linalg.LinAlgError):          # unconverged at the cap
+        lqr.discreteInfiniteHorizonLqr(A, B, Q, R, maxIter=3)
+    Lc, _, itc = lqr.discreteInfiniteHorizonLqr(A, B, Q, R, maxIter=3, return_value=True)
+    assert np.all(itc == -3)
+    Af, Bf, Qf, Rf = problems.tile_over_horizon(A, B, Q, R, 4)
+    Lf = lqr.discreteFiniteHorizonLqr(Af, Bf, Qf, Rf, 4)
+    assert np.max(np.abs(Lc - Lf[:, 1])) <= 1e-11 * np.max(np.abs(Lc))     # 3 iterations from V = Q = the gain at step T-3 of a 4-step horizon

@@ -304,7 +304,9 @@ namespace zm {
 int lqr_backward_lds_dispatch(const double* A, const double* B, const double* Q, const double* R, double* L, int64_t batch,
                               int T, int n, int m, hipStream_t st);   // lqr_backward_lds_f64.hip
 int lqr_backward_tiled_f64_dispatch(const double* A, const double* B, const double* Q, const double* R, double* L, int64_t batch,
-                                    int T, int n, int m, hipStream_t st);   // lqr_backward_tiled_f64.hip (n <= 48)
+                                    int T, int n, int m, hipStream_t st);   // lqr_backward_tiled_f64.hip (n <= 64)
+int lqr_dare_tiled_f64_dispatch(const double* A, const double* B, const double* Q, const double* R, double* L, double* P, int* iters,
+                                int64_t batch, int n, int m, double tol, int max_iter, hipStream_t st);
 }
 
 extern "C" int zm_lqr_backward_supported(int n, int m, int elem_size) {
@@ -359,8 +361,10 @@ extern "C" int zm_dare_f64(const double* A, const double* B, const double* Q, co
     if (batch == 0) return ZM_OK;   /* empty batch: nothing to do (pointers of empty arrays may be NULL) */
     if (!A || !B || !Q || !R || !L) return zm::set_error(ZM_EINVAL, "zm_dare_f64: null pointer");
     if (batch < 0 || n < 1 || m < 1 || max_iter < 1 || !(tol >= 0.0)) return zm::set_error(ZM_EINVAL, "zm_dare_f64: bad argument");
-    if (n > 12 || m > 4) return zm::set_error(ZM_EUNSUPPORTED, "zm_dare_f64: (n=%d, m=%d) not covered (need n<=12, m<=4)", n, m);
+    if (n > 64 || m > 16) return zm::set_error(ZM_EUNSUPPORTED, "zm_dare_f64: (n=%d, m=%d) not covered (need n<=64, m<=16)", n, m);
     if (batch >= ((int64_t)1 << 31)) return zm::set_error(ZM_EUNSUPPORTED, "zm_dare_f64: batch too large");
+    if (n > 12 || m > 4)   // large states: the fp64 tile kernel's step on time-invariant operands
+        return zm::lqr_dare_tiled_f64_dispatch(A, B, Q, R, L, P, (int*)iters, batch, n, m, tol, max_iter, (hipStream_t)stream);
     if (batch == 0) return ZM_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)batch), block(64);

@@ -17,4 +17,15 @@ int lqr_backward_tiled_f64_dispatch(const double* A, const double* B, const doub
     if (n <= 48) return launch_tiled<TileF64, 3>(A, B, Q, R, L, batch, T, n, m, st);
     return launch_tiled<TileF64, 4, false>(A, B, Q, R, L, batch, T, n, m, st);
 }
+
+// discreteInfiniteHorizonLqr beyond the tile-16 shapes (12 < n <= 64 or 4 < m <= 16): the tile kernel's Joseph-form step iterated on
+// time-invariant operands (lqr_tiled_core.h: DARE)
+int lqr_dare_tiled_f64_dispatch(const double* A, const double* B, const double* Q, const double* R, double* L, double* P, int* iters,
+                                int64_t batch, int n, int m, double tol, int max_iter, hipStream_t st) {
+    if (n > 64 || m > 16 || n < 1 || m < 1) return ZM_EUNSUPPORTED;
+    if (n <= 16) return launch_tiled_dare<TileF64, 1>(A, B, Q, R, L, P, iters, batch, max_iter, n, m, tol, st);
+    if (n <= 32) return launch_tiled_dare<TileF64, 2>(A, B, Q, R, L, P, iters, batch, max_iter, n, m, tol, st);
+    if (n <= 48) return launch_tiled_dare<TileF64, 3>(A, B, Q, R, L, P, iters, batch, max_iter, n, m, tol, st);
+    return launch_tiled_dare<TileF64, 4, false>(A, B, Q, R, L, P, iters, batch, max_iter, n, m, tol, st);
+}
 }  // namespace zm

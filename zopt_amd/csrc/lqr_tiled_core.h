@@ -260,11 +260,22 @@ __device__ unsigned long long zm_tiled_stamps[12];
 // PREFETCH: the operands of step k-1 are fetched into a second register set (Fn, Rn) while step k computes.  false (fp64 at four tile
 // rows, where V + F + Y alone take 448 of the 512 registers): the step's operands are loaded at its head instead -- the HBM latency
 // of one step's loads is exposed once per ~20 us step, which costs far less than spilling a second operand set.
-template <class TR, int NT, bool EXACT, bool PREFETCH = true>
+// DARE (discreteInfiniteHorizonLqr for large states, zopt/lqrUtils.py:176-204): the same step iterated on TIME-INVARIANT operands -- A, B,
+// Q, R are (batch, ., .) without a time axis, T is the iteration cap, L (batch, m, n) is overwritten every iteration -- from V = Q until
+// the gain stops changing: max|L_k - L_{k-1}| <= tol max|L_k| (tested every 8th iteration, or a stall at the rounding floor); then
+// P <- V (batch, n, n) and iters <- +k (converged) / -k (cap reached), as zm_dare_f64 documents.
+template <class S>
+struct TiledDareArgs {
+    S* P;
+    int* iters;
+    S tol;
+};
+
+template <class TR, int NT, bool EXACT, bool PREFETCH = true, bool DARE = false>
 __global__ __launch_bounds__(64) void lqr_backward_tiled(const typename TR::S* __restrict__ A, const typename TR::S* __restrict__ B,
                                                          const typename TR::S* __restrict__ Q, const typename TR::S* __restrict__ R,
                                                          typename TR::S* __restrict__ L, const long batch, const int T, const int n_,
-                                                         const int m_) {
+                                                         const int m_, const TiledDareArgs<typename TR::S> dr = {nullptr, nullptr, 0}) {
     using S = typename TR::S;
     using f4 = typename TR::V4;
     constexpr int TLD = TR::TLD;
@@ -283,11 +294,13 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled(const typename TR::S* _
     const long traj = blockIdx.x;
     if (traj >= batch) return;
     const long nn = (long)n * n, nm = (long)n * m, mm = (long)m * m;
-    const S* Ab = A + traj * T * nn;
-    const S* Bb = B + traj * T * nm;
-    const S* Qb = Q + traj * T * nn;
-    const S* Rb = R + traj * T * mm;
-    S* Lb = L + traj * T * nm;
+    const long TS = DARE ? 1 : T;              // operands per trajectory along the time axis
+    const S* Ab = A + traj * TS * nn;
+    const S* Bb = B + traj * TS * nm;
+    const S* Qb = Q + traj * TS * nn;
+    const S* Rb = R + traj * TS * mm;
+    S* Lb = L + traj * TS * nm;
+    const long k0 = DARE ? 0 : (long)(T - 1);  // time index of the first step
 
     f4 V[NT][NT], F[NT][NT + 1], Fn[PREFETCH ? NT : 1][NT + 1], Y[NT][NT + 1], Rt, Rn;
     // terminal value = last stage cost (lqrUtils.py:172); operands of the first step
@@ -295,18 +308,28 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled(const typename TR::S* _
     for (int K = 0; K < NT; ++K) {
 #pragma unroll
         for (int J = 0; J < NT; ++J) {
-            V[K][J] = load_tile<TR, EXACT>(Qb + (long)(T - 1) * nn, n, n, K, J, g, c);
-            if constexpr (PREFETCH) Fn[K][J] = load_tile<TR, EXACT>(Ab + (long)(T - 1) * nn, n, n, K, J, g, c);
+            V[K][J] = load_tile<TR, EXACT>(Qb + k0 * nn, n, n, K, J, g, c);
+            if constexpr (PREFETCH) Fn[K][J] = load_tile<TR, EXACT>(Ab + k0 * nn, n, n, K, J, g, c);
         }
-        if constexpr (PREFETCH) Fn[K][NT] = load_tile<TR, EXACT>(Bb + (long)(T - 1) * nm, n, m, K, 0, g, c);
+        if constexpr (PREFETCH) Fn[K][NT] = load_tile<TR, EXACT>(Bb + k0 * nm, n, m, K, 0, g, c);
     }
-    if constexpr (PREFETCH) Rn = load_tile<TR, EXACT>(Rb + (long)(T - 1) * mm, m, m, 0, 0, g, c, S(1));
+    if constexpr (PREFETCH) Rn = load_tile<TR, EXACT>(Rb + k0 * mm, m, m, 0, 0, g, c, S(1));
+    // DARE: the previous iteration's gain (this lane's column), convergence state
+    S xprev[DARE ? 16 : 1];
+    S dprev = TR::huge();
+    int stall = 0, iters_done = 0;
+    bool stop = false, conv = false;
+    if constexpr (DARE) {
+#pragma unroll
+        for (int u_ = 0; u_ < 16; ++u_) xprev[u_] = S(0);
+    }
 
 #ifdef ZM_TILED_LAB
     unsigned long long zt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, zt_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(zt_last)::"memory");
 #endif
-    for (int k = T - 1; k >= 0; --k) {
+    for (int kk_ = T - 1; kk_ >= 0; --kk_) {
+        const int k = DARE ? 0 : kk_;          // time index of this step's operands and of L_k
         if constexpr (PREFETCH) {
 #pragma unroll
             for (int K = 0; K < NT; ++K)
@@ -526,6 +549,37 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled(const typename TR::S* _
             t_lds_sync();
 #undef S_
         }
+        if constexpr (DARE) {   // has the gain stopped changing?  (wave-uniform decision; the step is finished either way)
+            ++iters_done;
+            if ((iters_done & 7) == 0 || kk_ == 0) {
+                S dmax = S(0), smax = S(0);
+#pragma unroll
+                for (int u_ = 0; u_ < 16; ++u_) {
+                    const S d_ = TR::abs(x[u_] - xprev[u_]), a_ = TR::abs(x[u_]);
+                    dmax = (lane < n && d_ > dmax) || (lane < n && !(d_ == d_)) ? d_ : dmax;      // NaN sticks
+                    smax = (lane < n && a_ > smax) ? a_ : smax;
+                }
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const S od = __shfl_xor(dmax, off, 64), os = __shfl_xor(smax, off, 64);
+                    dmax = (od > dmax || !(od == od)) ? od : dmax;
+                    smax = os > smax ? os : smax;
+                }
+                if (!(dmax > dr.tol * smax)) {           // converged (or NaN: stop; the caller sees the non-finite gain)
+                    conv = true;
+                    stop = true;
+                } else {
+                    stall = (dmax >= dprev && dmax <= S(1e-9) * smax) ? stall + 1 : 0;   // rounding floor reached
+                    if (stall >= 3) {
+                        conv = true;
+                        stop = true;
+                    }
+                    dprev = dmax;
+                }
+            }
+#pragma unroll
+            for (int u_ = 0; u_ < 16; ++u_) xprev[u_] = x[u_];
+        }
         // L_k to HBM (row u: 64 consecutive floats across the wave), -L back to LDS (b128) for the tile reads
         if (lane < n) {
 #pragma unroll
@@ -545,7 +599,7 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled(const typename TR::S* _
         ZT_STAMP(4)   // L store, -L through LDS back as tiles
         if constexpr (PREFETCH) {  // operands of step k-1, fetched under the ~15k cycles of MFMAs that follow (the last iteration
            // re-reads step 0: no branch around the loads); issued only now so that they do not hold 84 registers during the solve
-            const int kn = k > 0 ? k - 1 : 0;
+            const int kn = (!DARE && k > 0) ? k - 1 : 0;
 #pragma unroll
             for (int K = 0; K < NT; ++K) {
 #pragma unroll
@@ -585,6 +639,23 @@ __global__ __launch_bounds__(64) void lqr_backward_tiled(const typename TR::S* _
             }
         t_lds_sync();  // Sc / Tb are rewritten by the next step
         ZT_STAMP(6)   // -RL, Acl, W, V' (464 MFMAs)
+        if constexpr (DARE) {
+            if (stop) break;
+        }
+    }
+    if constexpr (DARE) {
+        if (dr.P) {
+#pragma unroll
+            for (int K = 0; K < NT; ++K)
+#pragma unroll
+                for (int J = 0; J < NT; ++J)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * K + TR::row(g, r), j = 16 * J + c;
+                        if (i < n && j < n) dr.P[traj * nn + (long)i * n + j] = V[K][J][r];
+                    }
+        }
+        if (dr.iters && lane == 0) dr.iters[traj] = conv ? iters_done : -iters_done;
     }
 #ifdef ZM_TILED_LAB
     if (lane == 0) {
@@ -605,6 +676,18 @@ static int launch_tiled(const typename TR::S* A, const typename TR::S* B, const 
     else
         hipLaunchKernelGGL((lqr_backward_tiled<TR, NT, false, PREFETCH>), dim3((unsigned)batch), dim3(64), 0, st, A, B, Q, R, L,
                            (long)batch, T, n, m);
+    ZM_HIP_CHECK(hipGetLastError());
+    return ZM_OK;
+}
+
+// DARE launcher (fp64): value iteration on time-invariant operands, see TiledDareArgs
+template <class TR, int NT, bool PREFETCH = true>
+static int launch_tiled_dare(const typename TR::S* A, const typename TR::S* B, const typename TR::S* Q, const typename TR::S* R,
+                             typename TR::S* L, typename TR::S* P, int* iters, int64_t batch, int max_iter, int n, int m,
+                             typename TR::S tol, hipStream_t st) {
+    const TiledDareArgs<typename TR::S> dr{P, iters, tol};
+    hipLaunchKernelGGL((lqr_backward_tiled<TR, NT, false, PREFETCH, true>), dim3((unsigned)batch), dim3(64), 0, st, A, B, Q, R, L,
+                       (long)batch, max_iter, n, m, dr);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }

@@ -107,7 +107,9 @@ def discreteInfiniteHorizonLqr(A, B, Q, R, tol=1e-14, maxIter=200000, return_val
 
     Arguments
     ---------
-        A : (..., n, n)    B : (..., n, m)    Q : (..., n, n)    R : (..., m, m)     (n <= 12, m <= 4)
+        A : (..., n, n)    B : (..., n, m)    Q : (..., n, n)    R : (..., m, m)     (n <= 64, m <= 16: the tile-16 register
+            kernel up to n <= 12, m <= 4, the fp64 MFMA tile kernel on time-invariant operands beyond -- it stops when the GAIN no
+            longer changes, `max|L_k - L_{k-1}| <= tol max|L_k|`)
 
     Returns
     -------
