@@ -30,7 +30,7 @@ def _load(path):
 
 
 def test_fixture_files_present_and_labelled():
-    assert len(FILES) == 3
+    assert len(FILES) == 4
     for f in FILES:
         z = np.load(f, allow_pickle=False)
         assert "reference source" in str(z["label"]) and "NumPy semantics" in str(z["label"])

@@ -34,7 +34,7 @@ def fx(request):
 
 
 def test_fixtures_exist():
-    assert len(FILES) == 3
+    assert len(FILES) == 4
 
 
 def test_A1_discreteFiniteHorizonLqr(fx):
