@@ -429,8 +429,8 @@ def overlapped_gather_leg(work, comm, reps=3):
     return out
 
 
-def workload_line(work, args, comm, total, elapsed, kern_ms, nev, steps, warmup):
-    """The per-workload part of the result line (rank 0)."""
+def workload_line(work):
+    """Metric name, workload description and (batch, T, n, m) of the result line (rank 0)."""
     from tools import workloads as wl
     b, T, n, m = getattr(work, "shape", (work.units_per_step, None, None, None))
     spec = wl.SPECS[work.name]
@@ -506,7 +506,7 @@ def run_rank(args):
         sharded = sharded_secondary(args, comm, world, rank, local_rank, work)
 
     if rank == 0:
-        metric, what, (batch, T, n, m) = workload_line(work, args, comm, total, elapsed, kern_ms, nev, steps, warmup)
+        metric, what, (batch, T, n, m) = workload_line(work)
         res = {
             "metric": metric,
             "value": job_units * steps / elapsed,
