@@ -263,6 +263,10 @@ def parse_args(argv):
     ap.add_argument("--force-dist", action="store_true",
                     help="N = 1: initialise a one-rank process group all the same, so that the gather legs (RCCL all-gather, chunked "
                          "overlapped gather) run on the one GPU a builder has")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a box with fewer GPUs than ranks: rank r runs its HIP workload on GPU r %% device_count (several "
+                         "processes share a device; RCCL refuses that, so use --backend gloo: collectives are staged through host memory). "
+                         "Exercises the REAL sharded kernels and gathers; its timings are not measurements")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo with --stub-step for the CPU rehearsal)")
     ap.add_argument("--stub-step", action="store_true", help="CPU stand-in for the HIP launch (harness rehearsal; not a measurement)")
     ap.add_argument("--stub-fail-rank", type=int, default=-1, help="(stub only) this rank raises in its first step: failure-propagation test")
@@ -276,6 +280,7 @@ class Comm:
     def __init__(self, dist, world, dev):
         self.dist, self.world, self.dev = dist, world, dev
         self.on = dist.is_initialized()
+        self.host_staged = False
 
     def barrier(self):
         if self.on:
@@ -352,6 +357,8 @@ def gather_leg(work, comm, rank):
     ok, err, packed, fields = 1.0, None, None, work.results()
     try:
         packed = fields[0].contiguous() if len(fields) == 1 else zdist.pack_results(fields)
+        if comm.host_staged:
+            packed = packed.cpu()
     except Exception as e:  # noqa: BLE001
         ok, err = 0.0, f"{type(e).__name__}: {e}"
     if comm.reduce(ok, "min") < 1.0:
@@ -386,6 +393,8 @@ def overlapped_gather_leg(work, comm, reps=3):
     the next chunk's sweep (zopt_amd.dist.ChunkedGather), against the same launches followed by ONE gather of the whole shard."""
     import torch
     from zopt_amd import dist as zdist
+    if comm.host_staged:
+        return {"skipped": "host-staged collectives (gloo rehearsal of HIP workloads): nothing to overlap"}
     L = work.results()[0]
     nch = work.nchunks
     counts = zdist.shard_counts(L.shape[0])
@@ -480,12 +489,20 @@ def run_rank(args):
             dist.init_process_group("gloo")
     formed = dist.get_world_size() if dist.is_initialized() else 1
 
+    if args.share_gpu:
+        if args.backend != "gloo" and world > 1:
+            raise SystemExit("bench.py: --share-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     spec = wl.SPECS[args.workload]
     steps = args.steps if args.steps is not None else spec["steps"]
     warmup = args.warmup if args.warmup is not None else spec["warmup"]
     work, total = wl.make(args.workload, args.scaling, world, rank, local_rank, batch=args.batch, stub=args.stub_step,
                           stub_fail_rank=args.stub_fail_rank, T=args.T, n=args.n, m=args.m)
-    comm = Comm(dist, world, work.dev)
+    # gloo moves host memory: with real (HIP) workloads under --backend gloo the harness' scalars and the gathered results are staged
+    # through the CPU (rehearsal); RCCL takes device tensors directly
+    host_staged = (args.backend == "gloo") and not work.stub
+    comm = Comm(dist, world, torch.device("cpu") if host_staged else work.dev)
+    comm.host_staged = host_staged
     elapsed, kern_ms, nev = timed_steps(work, comm, steps, warmup, args.prewarm_ms)
     job_units = comm.reduce(float(work.units_per_step), "sum")      # ragged shards: the job's units are the sum over ranks
     devices = comm.names(work.device_name())
