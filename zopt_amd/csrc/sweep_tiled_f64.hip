@@ -25,6 +25,7 @@
 // Not tuned like K1-T (no operand prefetch, no MFMA / VALU interleave): it lifts the shape limit of the tile-16 kernels
 // (ilqr_backward.hip: n <= 12, m <= 4) for the array-level sweeps; measured rates in DESIGN.md.
 #include "lqr_tiled_core.h"
+#include "tile16_f64.h"
 
 namespace zm {
 
@@ -48,7 +49,10 @@ struct SweepTiledArgs {
     double *v_out, *vx_out, *vxx_out;
 };
 
-template <int NT, int MODE>
+// M4: m <= 4 -- the m x m solve is then the lane-local 4 x 4 elimination of the tile-16 kernels (tile16_f64.h: every lane reads the
+// 4 x 4 block of Q_uu by broadcast and eliminates its own right-hand-side column, ~60 instructions) instead of the 16 x 16 register
+// solve (~1 300): at (16, 4) the solve was two thirds of the step.
+template <int NT, int MODE, bool M4>
 __global__ __launch_bounds__(64) void sweep_tiled_f64(const SweepTiledArgs a) {
     using TR = TileF64;
     using f4 = td4;
@@ -93,22 +97,64 @@ __global__ __launch_bounds__(64) void sweep_tiled_f64(const SweepTiledArgs a) {
     t_lds_sync();
     double vs = (MODE == 0 && a.v_out && a.vf) ? a.vf[traj] : 0.0;   // scalar part of the value function (wave-uniform)
 
-    for (int k = T - 1; k >= 0; --k) {
-        // ---- operands of the step: F = [f_x | f_u] and the stacked cost Hessian as the accumulator init of G
-        f4 F[NT][NT + 1], G[NT][NT], Gu[NT + 1];
+    // operands of a step: F = [f_x | f_u], the stacked cost Hessian (accumulator init of G), the cost gradients at this lane's
+    // column / control.  They do not depend on the recursion: step k-1's are fetched into a second register set while step k computes.
+    // (three tile rows: the second set would be 200 more registers and the compiler spills them -- there the operands are loaded at
+    //  the head of their own step, as the LQR tile kernel does at four tile rows)
+    constexpr bool PF = NT <= 2;
+    f4 Fn[PF ? NT : 1][NT + 1], Gn[PF ? NT : 1][NT], Gun[PF ? NT + 1 : 1];
+    double gxn = 0.0, gun = 0.0;
+    auto fetch = [&](const int k, f4 (&Fd)[PF ? NT : 1][NT + 1], f4 (&Gd)[PF ? NT : 1][NT], f4 (&Gud)[PF ? NT + 1 : 1], double& gxd, double& gud) {
+        if constexpr (PF) {
 #pragma unroll
-        for (int K = 0; K < NT; ++K) {
+            for (int K = 0; K < NT; ++K) {
 #pragma unroll
-            for (int J = 0; J < NT; ++J) {
-                F[K][J] = load_tile<TR, false>(fxb + k * nn, n, n, K, J, g, c);
-                G[K][J] = load_tile<TR, false>(cxxb + hs * k * nn, n, n, K, J, g, c);
+                for (int J = 0; J < NT; ++J) {
+                    Fd[K][J] = load_tile<TR, false>(fxb + k * nn, n, n, K, J, g, c);
+                    Gd[K][J] = load_tile<TR, false>(cxxb + hs * k * nn, n, n, K, J, g, c);
+                }
+                Fd[K][NT] = load_tile<TR, false>(fub + k * nm, n, m, K, 0, g, c);
+                Gud[K] = load_tile<TR, false>(cuxb + hs * k * nm, m, n, 0, K, g, c);
             }
-            F[K][NT] = load_tile<TR, false>(fub + k * nm, n, m, K, 0, g, c);
-            Gu[K] = load_tile<TR, false>(cuxb + hs * k * nm, m, n, 0, K, g, c);
+            Gud[NT] = load_tile<TR, false>(cuub + hs * k * mm, m, m, 0, 0, g, c, 1.0);   // padded controls: identity pivots
+            gxd = lane < n ? cxb[k * n + lane] : 0.0;                                    // c_x resp. q at this lane's column
+            gud = c < m ? cub[k * m + c] : 0.0;                                          // c_u resp. r at this lane's control
         }
-        Gu[NT] = load_tile<TR, false>(cuub + hs * k * mm, m, m, 0, 0, g, c, 1.0);   // padded controls: identity pivots
-        const double gx = lane < n ? cxb[k * n + lane] : 0.0;                       // c_x resp. q at this lane's column
-        const double gu = c < m ? cub[k * m + c] : 0.0;                             // c_u resp. r at this lane's control
+    };
+    if constexpr (PF) fetch(T - 1, Fn, Gn, Gun, gxn, gun);
+    for (int k = T - 1; k >= 0; --k) {
+        f4 F[NT][NT + 1], G[NT][NT], Gu[NT + 1];
+        double gx, gu;
+        if constexpr (PF) {
+#pragma unroll
+            for (int K = 0; K < NT; ++K) {
+#pragma unroll
+                for (int J = 0; J < NT; ++J) {
+                    F[K][J] = Fn[K][J];
+                    G[K][J] = Gn[K][J];
+                }
+                F[K][NT] = Fn[K][NT];
+                Gu[K] = Gun[K];
+            }
+            Gu[NT] = Gun[NT];
+            gx = gxn;
+            gu = gun;
+            fetch(k > 0 ? k - 1 : 0, Fn, Gn, Gun, gxn, gun);   // (the last iteration re-reads step 0: no branch around the loads)
+        } else {
+#pragma unroll
+            for (int K = 0; K < NT; ++K) {
+#pragma unroll
+                for (int J = 0; J < NT; ++J) {
+                    F[K][J] = load_tile<TR, false>(fxb + k * nn, n, n, K, J, g, c);
+                    G[K][J] = load_tile<TR, false>(cxxb + hs * k * nn, n, n, K, J, g, c);
+                }
+                F[K][NT] = load_tile<TR, false>(fub + k * nm, n, m, K, 0, g, c);
+                Gu[K] = load_tile<TR, false>(cuxb + hs * k * nm, m, n, 0, K, g, c);
+            }
+            Gu[NT] = load_tile<TR, false>(cuub + hs * k * mm, m, m, 0, 0, g, c, 1.0);
+            gx = lane < n ? cxb[k * n + lane] : 0.0;
+            gu = c < m ? cub[k * m + c] : 0.0;
+        }
 
         // ---- vector terms (they need V BEFORE its update): the vector(s) at this lane's tile rows 16 K + 4 r + g
         double tr_[NT][4], sr_[NT][4];   // multiplied into the f_x columns / into the f_u columns
@@ -210,6 +256,19 @@ __global__ __launch_bounds__(64) void sweep_tiled_f64(const SweepTiledArgs a) {
             u[i] = Sc[(UC + c) * TLD + i];
             if constexpr (MODE == 1) x0[i] = x[i];
         }
+      if constexpr (M4) {
+        // m <= 4: the 4 x 4 block of Q_uu (rows / columns >= m are identity padding) by broadcast reads, this lane's right-hand side
+        double S4[4][4], b4[4], x4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) S4[i][jj] = Sc[(UC + jj) * TLD + i];
+            b4[i] = x[i];
+        }
+        if (__builtin_amdgcn_ballot_w64(!lu_solve4_nopivot(S4, b4, x4)) != 0ull) lu_solve4_fallback(S4, b4, x4);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = i < 4 ? x4[i] : 0.0;
+      } else {
         // ---- LU without row exchanges on registers (row operations are lane-local, the multipliers wave-uniform)
         unsigned long long bad = 0ull;
         double pinv[16];
@@ -297,6 +356,7 @@ __global__ __launch_bounds__(64) void sweep_tiled_f64(const SweepTiledArgs a) {
             t_lds_sync();
 #undef S_
         }
+      }
         // x = column `lane` of Xs = Q_uu^-1 Q_ux (lanes < NP); lane NP: xs = Q_uu^-1 Q_u.  The policy of this step:
         constexpr double sgn = MODE == 0 ? -1.0 : 1.0;   // ilqrUtils.py:167-168 negates, lqrUtils.py:248-249 does not
         if (lane < n) {
@@ -378,10 +438,15 @@ __global__ __launch_bounds__(64) void sweep_tiled_f64(const SweepTiledArgs a) {
 template <int NT>
 static int launch_sweep_tiled(int mode, const SweepTiledArgs& a, long nslot, hipStream_t st) {
     const dim3 grid((unsigned)nslot), block(64);
-    if (mode == 0)
-        hipLaunchKernelGGL((sweep_tiled_f64<NT, 0>), grid, block, 0, st, a);
+    const bool m4 = a.m <= 4;
+    if (mode == 0 && m4)
+        hipLaunchKernelGGL((sweep_tiled_f64<NT, 0, true>), grid, block, 0, st, a);
+    else if (mode == 0)
+        hipLaunchKernelGGL((sweep_tiled_f64<NT, 0, false>), grid, block, 0, st, a);
+    else if (m4)
+        hipLaunchKernelGGL((sweep_tiled_f64<NT, 1, true>), grid, block, 0, st, a);
     else
-        hipLaunchKernelGGL((sweep_tiled_f64<NT, 1>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((sweep_tiled_f64<NT, 1, false>), grid, block, 0, st, a);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }
