@@ -35,7 +35,8 @@ namespace zm {
 // ----------------------------------------------------------------------------------------------------------------
 // setup: single workgroup, matrices in LDS, threads spread over matrix elements
 // ----------------------------------------------------------------------------------------------------------------
-constexpr int SN = 12, SM = 4;
+constexpr int SN = 12, SM = 4;      // the shapes of the 16-lanes-per-instance kernel (mpc_wave.hip) and of the small lane kernels
+constexpr int SNL = 24, SML = 8;    // larger problems: the lane-per-instance kernel only (fixed penalty), see zm_mpc_solve_relaxed_f64
 
 __device__ __forceinline__ void mm_nn(double* C, const double* A, const double* B, int p, int q, int r) {  // C = A(p,q) B(q,r)
     for (int e = threadIdx.x; e < p * r; e += blockDim.x) {
@@ -56,6 +57,7 @@ __device__ __forceinline__ void mm_tn(double* C, const double* A, const double* 
     __syncthreads();
 }
 
+template <int SN, int SM>
 __global__ __launch_bounds__(256) void mpc_setup_kernel(const double* __restrict__ A, const double* __restrict__ B,
                                                         const double* __restrict__ Q, const double* __restrict__ R,
                                                         const double* __restrict__ Qf, const double rho, const int N,
@@ -446,9 +448,13 @@ extern "C" int zm_mpc_setup_f64(const double* A, const double* B, const double* 
                                 double rho, int N, int n, int m, double* K, double* Minv, void* stream) {
     if (!A || !B || !Q || !R || !Qf || !K || !Minv) return zm::set_error(ZM_EINVAL, "zm_mpc_setup_f64: null pointer");
     if (N < 1 || n < 1 || m < 1 || !(rho > 0.0)) return zm::set_error(ZM_EINVAL, "zm_mpc_setup_f64: bad size / rho");
-    if (n > zm::SN || m > zm::SM) return zm::set_error(ZM_EUNSUPPORTED, "zm_mpc_setup_f64: (n=%d, m=%d) not covered", n, m);
-    hipLaunchKernelGGL(zm::mpc_setup_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, A, B, Q, R, Qf, rho, N, n, m, K,
-                       Minv);
+    if (n > zm::SNL || m > zm::SML) return zm::set_error(ZM_EUNSUPPORTED, "zm_mpc_setup_f64: (n=%d, m=%d) not covered (n <= 24, m <= 8)", n, m);
+    if (n <= zm::SN && m <= zm::SM)
+        hipLaunchKernelGGL((zm::mpc_setup_kernel<zm::SN, zm::SM>), dim3(1), dim3(256), 0, (hipStream_t)stream, A, B, Q, R, Qf, rho, N, n,
+                           m, K, Minv);
+    else
+        hipLaunchKernelGGL((zm::mpc_setup_kernel<zm::SNL, zm::SML>), dim3(1), dim3(256), 0, (hipStream_t)stream, A, B, Q, R, Qf, rho, N, n,
+                           m, K, Minv);
     ZM_HIP_CHECK(hipGetLastError());
     return ZM_OK;
 }
@@ -513,6 +519,7 @@ extern "C" int zm_mpc_solve_relaxed_f64(const double* A, const double* B, const 
     }
     t.K = K + (long)level0 * N * m * n;
     t.Minv = Minv + (long)level0 * N * m * m;
+    if (n == 24 && m == 8) return zm::launch_mpc<24, 8>(t, g, st);   // beyond the 16-index tile: lane per instance, registers + scratch
     if (n == 12 && m == 4) return zm::launch_mpc<12, 4>(t, g, st);
     if (n == 8 && m == 4) return zm::launch_mpc<8, 4>(t, g, st);
     if (n == 4 && m == 2) return zm::launch_mpc<4, 2>(t, g, st);

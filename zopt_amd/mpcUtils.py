@@ -58,13 +58,13 @@ class lqrMpc():
         # one penalty for every instance: the geometric mean of the cost curvatures keeps both blocks of the
         # w-update Hessian (2Q + rho I, 2R + rho I) comparably conditioned
         self.rho = float(np.sqrt(max(np.trace(2 * self.Q) / self.n, 1e-12) * max(np.trace(2 * self.R) / self.m, 1e-12)))
-        # The solve kernels are compiled for a few (n, m); any other n <= 12, m <= 4 is embedded in the next one: the extra
+        # The solve kernels are compiled for a few (n, m); any other n <= 24, m <= 8 is embedded in the next one: the extra
         # states follow x+ = 0 from x = 0 with unit weight and no bound, the extra controls act on nothing and cost u^2 --
         # they stay exactly zero and are sliced off the results.
         self._n_user, self._m_user = self.n, self.m
         fit = [(ns, mc) for (ns, mc) in self._COMPILED if ns >= self.n and mc >= self.m]
         if not fit:
-            raise ValueError(f"lqrMpc: (n={self.n}, m={self.m}) outside the compiled kernels (n <= 12, m <= 4)")
+            raise ValueError(f"lqrMpc: (n={self.n}, m={self.m}) outside the compiled kernels (n <= 24, m <= 8)")
         ns, mc = min(fit, key=lambda t: (t[0] * t[1], t[0]))
         if (ns, mc) != (self.n, self.m):
             n0, m0 = self.n, self.m
@@ -81,7 +81,9 @@ class lqrMpc():
             self.u_ub = np.concatenate([self.u_ub, np.full(mc - m0, inf)])
             self.n, self.m = ns, mc
 
-    _COMPILED = ((12, 4), (8, 4), (4, 2), (4, 1), (2, 2), (2, 1), (1, 1))
+    # (24, 8): beyond the 16-index tile of the 16-lanes-per-instance kernel -- the lane-per-instance kernel with a fixed penalty (no
+    # tabulated levels): a coverage path, an order of magnitude slower per instance than the (12, 4) kernels
+    _COMPILED = ((24, 8), (12, 4), (8, 4), (4, 2), (4, 1), (2, 2), (2, 1), (1, 1))
 
     N_LEVELS, RHO_STEP = 7, 5.0      # adaptive penalty: rho * 5^(l - 3), l = 0..6  (OSQP changes rho only by factors >= 5)
 
