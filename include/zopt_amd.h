@@ -350,7 +350,10 @@ int zm_condition_dynamics_f64(const double* f_xx, const double* f_ux, const doub
                                        "infeasible_inaccurate" is reported as "user_limit" (an uncertified instance at the cap) */
 
 /* Riccati tables of the ADMM w-update for penalty rho:  K (N,m,n), Minv (N,m,m)   [all device pointers]
- * in : A (n,n) B (n,m) Q (n,n) R (m,m) Qf (n,n) */
+ * in : A (n,n) B (n,m) Q (n,n) R (m,m) Qf (n,n); n <= 24, m <= 8.
+ * Shapes of the solve entry points: (n, m) in {(12,4), (8,4), (4,2), (4,1), (2,2), (2,1), (1,1)} (16 lanes per instance, adaptive penalty
+ * levels; the Python mirror embeds any smaller shape with inert padding) and (24, 8) (one lane per instance, the penalty of `level0`
+ * only; registers + scratch: a coverage path for problems beyond the 16-index tile). */
 int zm_mpc_setup_f64(const double* A, const double* B, const double* Q, const double* R, const double* Qf, double rho,
                      int N, int n, int m, double* K, double* Minv, void* stream);
 
