@@ -382,8 +382,8 @@ int zm_mpc_solve_warm_f64(const double* A, const double* B, const double* K, con
 
 /* Same, with OSQP's adaptive penalty (`adaptive_rho`, on by default in OSQP / cvxpy): K and Minv hold the tables of
  * zm_mpc_setup_f64 for n_levels penalties rho * rho_step^(l - level0), level-major (n_levels, N, m, n) / (n_levels, N, m, m).
- * Every 25 iterations an instance moves to the level nearest rho * sqrt(primal / dual residual ratio) when that is at least a
- * factor rho_step away, rescaling its scaled dual.  n_levels = 1 is the fixed-penalty solve above. */
+ * Every 8 iterations an instance moves to the level nearest (on the log scale) rho * sqrt(primal / dual residual ratio),
+ * rescaling its scaled dual.  n_levels = 1 is the fixed-penalty solve above. */
 int zm_mpc_solve_adaptive_f64(const double* A, const double* B, const double* K, const double* Minv, int n_levels, int level0,
                               double rho_step, const double* x_lb, const double* x_ub, const double* u_lb, const double* u_ub,
                               const double* x0, double rho, double eps_abs, double eps_rel, double eps_prim_inf, int max_iter,

@@ -15,6 +15,8 @@ from __future__ import annotations
 import numpy as np
 import scipy.optimize as spo
 
+CHECK_EVERY = 8   # zopt_amd/csrc/mpc_common.h ZM_MPC_CHK: iterations between infeasibility-certificate checks
+
 
 def condense(A, B, Q, R, Qf, N, x0):
     """x_k = Phi_k x0 + sum_j Gam[k,j] u_j ;  cost = u'Hu + 2 g'u + c  in the stacked control vector u (N*m)."""
@@ -135,7 +137,7 @@ def admm(A, B, Q, R, Qf, N, x_lb, x_ub, u_lb, u_ub, x0, rho=1.0, eps_abs=1e-5, e
     status, it = "user_limit", 0
     x, u = None, None
     for it in range(1, max_iter + 1):
-        chk = (it % 25) == 0
+        chk = (it % CHECK_EVERY) == 0
         zx, zu = yx - lx, yu - lu
         p = -rho * zx[N - 1]
         kf = np.zeros((N, m))

@@ -20,7 +20,7 @@
 // (OSQP-style criteria); a wave retires when all its lanes have.
 //
 // Termination (as OSQP): r_prim = |w - y|_inf <= eps_abs + eps_rel max(|w|,|y|),  r_dual = rho |y - y_prev|_inf <=
-// eps_abs + eps_rel rho |lam|.  Infeasibility: x0 outside its bounds; or, every 25 iterations, OSQP's primal
+// eps_abs + eps_rel rho |lam|.  Infeasibility: x0 outside its bounds; or, every ZM_MPC_CHK (8) iterations, OSQP's primal
 // infeasibility certificate on the dual step v = w - y:  |G^T v|_inf <= eps_pinf |v|_inf  (G = the linear map u -> w;
 // computed by an adjoint sweep) and  v^T w(u=0) - support_box(v) > eps_pinf |v|_inf,  i.e. v separates the dynamics
 // subspace from the box.  The certificate is sound but can need thousands of iterations; an infeasible instance that

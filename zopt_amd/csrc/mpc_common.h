@@ -3,9 +3,10 @@
 #include "zm_common.h"
 
 // Every ZM_MPC_CHK-th ADMM iteration checks the primal-infeasibility certificate and lets the adaptive penalty move (OSQP's
-// `check_termination` / `adaptive_rho_interval`, both tunables of the solver, not of the problem).
+// `check_termination` / `adaptive_rho_interval`, both tunables of the solver, not of the problem).  8 with moves to the NEAREST
+// tabulated level: measured on BASELINE configs[2] (profiles/r03_mpc_check_interval_ab.txt) 106 -> 60 worst-case iterations.
 #ifndef ZM_MPC_CHK
-#define ZM_MPC_CHK 25
+#define ZM_MPC_CHK 8
 #endif
 
 namespace zm {

@@ -319,15 +319,16 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
             }
         }
         // ---- adaptive penalty (OSQP adaptive_rho): rho <- rho sqrt(normalised primal / normalised dual residual), taken in
-        //      whole steps of the tabulated levels (factor rho_step, i.e. only when off by at least that factor); the scaled
-        //      dual lam = mu / rho is rescaled so that the unscaled multiplier mu is unchanged
+        //      whole steps of the tabulated levels: to the level nearest the wanted penalty on the log scale (so a move happens
+        //      when the penalty is off by at least sqrt(rho_step)); the scaled dual lam = mu / rho is rescaled so that the
+        //      unscaled multiplier mu is unchanged
         if (g.n_levels > 1 && chk && !done) {
             const double tiny = 1e-300;
             const double rpn = rp / __builtin_fmax(__builtin_fmax(nw, ny), tiny);
             const double rdn = rd / __builtin_fmax(rho * nl, tiny);
             const double want = __builtin_sqrt(rpn / __builtin_fmax(rdn, tiny));
             int dl = 0;
-            if (want == want && want > 0.0) dl = (int)(log(want) / log(g.rho_step));   // truncates toward 0
+            if (want == want && want > 0.0) dl = (int)lrint(log(want) / log(g.rho_step));   // the NEAREST tabulated level
             int nl_ = lvl + dl;
             nl_ = nl_ < 0 ? 0 : (nl_ >= g.n_levels ? g.n_levels - 1 : nl_);
             if (nl_ != lvl) {
