@@ -270,7 +270,12 @@ def parse_args(argv):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo with --stub-step for the CPU rehearsal)")
     ap.add_argument("--stub-step", action="store_true", help="CPU stand-in for the HIP launch (harness rehearsal; not a measurement)")
     ap.add_argument("--stub-fail-rank", type=int, default=-1, help="(stub only) this rank raises in its first step: failure-propagation test")
+    ap.add_argument("--stub-stall-rank", type=int, default=-1,
+                    help="(stub only) this rank never enters the legs after the headline: test of --optional-budget-s")
     ap.add_argument("--launch-timeout-s", type=float, default=1500.0, help="launcher: kill the ranks and fail after this long")
+    ap.add_argument("--optional-budget-s", type=float, default=420.0,
+                    help="N > 1: the legs after the headline (result gathers, strong-sharded configs[2..4]) get this long; "
+                         "after that rank 0 prints the headline line with an error entry for them and every rank exits")
     return ap.parse_args(argv)
 
 
@@ -458,6 +463,34 @@ def workload_line(work):
     return metric, what[work.name].format(b=b, T=T, n=n, m=m), (b, T, n, m)
 
 
+class OptionalLegsWatchdog:
+    """The legs that follow the headline at N > 1 (result all-gathers, the strong-sharded configs[2..4]) are collectives over every
+    rank: a rank that fails inside one leaves the others waiting.  That must not cost the run its headline, which is complete before
+    they start -- after `seconds` a timer thread lets rank 0 print the headline line with an error entry in place of the missing legs,
+    and ends the process (`os._exit`: the main thread may sit in a collective that never returns).  HIP synchronisation and c10d
+    collectives release the GIL, so the timer thread does run."""
+
+    def __init__(self, seconds, emit):
+        import threading
+        self.seconds, self.emit, self.stage = seconds, emit, "start"
+        self.timer = threading.Timer(seconds, self.fire)
+        self.timer.daemon = True
+
+    def start(self):
+        self.timer.start()
+
+    def cancel(self):
+        self.timer.cancel()
+
+    def fire(self):
+        msg = f"not finished {self.seconds:.0f} s after the headline (--optional-budget-s), last stage entered: {self.stage}"
+        print(f"bench.py: optional legs {msg}", file=sys.stderr, flush=True)
+        try:
+            self.emit(msg)
+        finally:
+            os._exit(0)
+
+
 def run_rank(args):
     # ONE JSON line on stdout, nothing else: RCCL prints a version banner to stdout when a communicator is created, gloo a connection
     # notice -- everything this process or its libraries print goes to stderr, the result line alone to the saved stdout
@@ -507,22 +540,11 @@ def run_rank(args):
     job_units = comm.reduce(float(work.units_per_step), "sum")      # ragged shards: the job's units are the sum over ranks
     devices = comm.names(work.device_name())
 
-    gather = None
-    if comm.on and not args.no_gather:
-        gather = gather_leg(work, comm, rank)
-        if args.workload == "n64" and "error" not in gather:
-            gather["overlap"] = overlapped_gather_leg(work, comm)
+    legs = {"gather": None, "sharded": None, "parity": None}
 
-    parity = None
-    if rank == 0 and args.workload == "lqr" and not work.stub and not args.no_parity:
-        parity = parity_of_timed_output(work)      # checker leg (oracle/riccati_oracle.c), after the timing; rank-local, no collective
-
-    # N > 1, headline workload: the configs BASELINE defines as multi-GPU, strong-sharded over the same ranks (every rank takes part)
-    sharded = None
-    if world > 1 and args.workload == "lqr" and not args.no_secondary:
-        sharded = sharded_secondary(args, comm, world, rank, local_rank, work)
-
-    if rank == 0:
+    def emit(optional_error=None):
+        """rank 0: the ONE result line, from what has been measured so far"""
+        gather, sharded, parity = legs["gather"], legs["sharded"], legs["parity"]
         metric, what, (batch, T, n, m) = workload_line(work)
         res = {
             "metric": metric,
@@ -592,14 +614,44 @@ def run_rank(args):
             torch.cuda.empty_cache()
             from tools import secondary_bench
             res["secondary"] = secondary_bench.run_all(args.secondary_budget_s)
+        if optional_error is not None:
+            res["optional_legs_error"] = optional_error
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(res) + "\n").encode())
+
+    dog = None
+    if comm.on and args.optional_budget_s > 0:
+        dog = OptionalLegsWatchdog(args.optional_budget_s, emit if rank == 0 else (lambda msg: None))
+        dog.start()
+    if args.stub_step and rank == args.stub_stall_rank:
+        time.sleep(3600.0)                    # the watchdog ends this rank too
+    if comm.on and not args.no_gather:
+        if dog:
+            dog.stage = "result all-gather of the headline workload"
+        legs["gather"] = gather_leg(work, comm, rank)
+        if args.workload == "n64" and "error" not in legs["gather"]:
+            legs["gather"]["overlap"] = overlapped_gather_leg(work, comm)
+
+    if rank == 0 and args.workload == "lqr" and not work.stub and not args.no_parity:
+        legs["parity"] = parity_of_timed_output(work)      # checker leg (oracle/riccati_oracle.c), after the timing; rank-local, no collective
+
+    # N > 1, headline workload: the configs BASELINE defines as multi-GPU, strong-sharded over the same ranks (every rank takes part)
+    if world > 1 and args.workload == "lqr" and not args.no_secondary:
+        legs["sharded"] = sharded_secondary(args, comm, world, rank, local_rank, work, dog)
     if dist.is_initialized():
+        if dog:
+            dog.stage = "closing barrier"
         dist.barrier()
+    if dog:
+        dog.cancel()
+    if rank == 0:
+        emit()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
-def sharded_secondary(args, comm, world, rank, local_rank, headline_work):
+
+def sharded_secondary(args, comm, world, rank, local_rank, headline_work, dog=None):
     """N > 1: configs[2], [3] (iLQR and DDP) and [4] strong-sharded over the ranks of this run -- every rank solves its
     `dist.shard_bounds` slice of the config's total through the same C-ABI calls as at N = 1, barrier + max-over-ranks timing, then
     the result all-gather (configs[4]: also chunked and overlapped with the sweep).  One driver SCALE pass over N = 1, 2, 4, 8 thus
@@ -616,6 +668,8 @@ def sharded_secondary(args, comm, world, rank, local_rank, headline_work):
     plan = (("mpc", 3, 1), ("ilqr", 3, 1), ("ddp", 2, 1), ("n64", 5, 2))
     for name, steps, warmup in plan:
         key = f"configs[{wl.SPECS[name]['config']}]_{name}"
+        if dog:
+            dog.stage = f"strong-sharded {key}"
         work, ok, err = None, 1.0, None
         try:
             work, total = wl.make(name, "strong", world, rank, local_rank, batch=(8 * world if args.stub_step else None),

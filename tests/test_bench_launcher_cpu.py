@@ -142,3 +142,16 @@ def test_strong_scaling_of_the_headline_and_force_dist():
     assert out.returncode == 0, out.stderr[-2000:]
     res = _one_json_line(out.stdout)          # no launcher in between: the rank itself keeps gloo's notice off stdout
     assert res["rccl_ranks"] == 1 and res["allgather"]["items"] == 4 and "overlap" in res["allgather"]
+
+
+def test_a_rank_stalling_after_the_headline_does_not_cost_the_line():
+    """the legs after the headline (result gathers, strong-sharded configs) are collectives: when one rank never arrives, rank 0 still
+    prints the headline line -- with an error entry for the legs -- once --optional-budget-s has passed, and every rank exits"""
+    out = _run([sys.executable, BENCH, "--gpus", "2", "--stub-stall-rank", "1", "--optional-budget-s", "4", "--launch-timeout-s", "120"]
+               + STUB, _clean_env())
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["value"] > 0 and "allgather" not in res
+    assert "optional_legs_error" in res and "all-gather" in res["optional_legs_error"]
