@@ -359,3 +359,47 @@ def test_packed_second_derivatives_match_the_full_tensors(mods):
     lin = models.LinearModel(np.eye(2), np.eye(2)).c_struct()
     assert lib.zm_quadratic_dynamics_pairs_list_f64(ctypes.addressof(lin), xT.data_ptr(), uT.data_ptr(), None, 0, None, H.data_ptr(), 1, 1,
                                                     st) == _lib.ZM_EUNSUPPORTED
+
+
+def test_ddp_follows_the_oracle_loop_iteration_by_iteration(mods):
+    """Twin of tests/test_ilqr_solve_gpu.py::test_iterativeLqr_non_converging_starts_follow_the_oracle_loop for the DDP driver
+    (ilqrUtils.py:360-397): zm_ilqr_solve_trace_f64's record of every iteration's accepted cost and winning step-size index against
+    `oracle.differentialDynamicProgramming(trace=...)` on the first 1024 of BASELINE configs[3]'s starts -- one start that converges
+    and, when the shard holds one, one that runs to maxIter.  The kernel projects with the matrix-sign iteration, the oracle with
+    `eigh` (1e-12 apart per matrix), so the two loops are the same computation up to rounding: same `converged`, the same iteration
+    count for the converging start, cost (1e-9) and step-size index equal for >= 10 leading iterations (count printed)."""
+    import warnings
+    from tests.test_ilqr_solve_gpu import _agreement
+    ilqr, models, _, _ = mods
+    batch, N = 1024, 100
+    Q, R, Qf = np.eye(12), 0.2 * np.eye(4), 10 * np.eye(12)
+    cost = models.QuadraticCost(Q, R, Qf)
+    rng = np.random.default_rng(2)
+    x0 = np.zeros((8192, 12))
+    x0[:, 9:12] = rng.uniform(-10, 10, (8192, 3))
+    x0 = x0[:batch]
+    ug = np.tile(models.QuadcopterEuler.uTrim, (batch, N, 1))
+    ilqr._TRACE = []
+    try:
+        traj, L, J, conv = ilqr.differentialDynamicProgramming(models.QuadcopterEuler(0.1), cost, cost, x0, ug)
+        rec = dict(ilqr._TRACE)
+    finally:
+        ilqr._TRACE = None
+    Jtr, atr = rec["J_trace"], rec["alpha_trace"]
+    assert Jtr.shape == (rec["iterations"], batch) and np.array_equal(Jtr[-1], J, equal_nan=True)
+    fn, ft = zo.quad_euler_step(0.1), zo.quad_euler_step_torch(0.1)
+    capped = np.flatnonzero(~conv)
+    picks = [("converges", int(np.flatnonzero(conv)[0]))] + ([("maxIter", int(capped[0]))] if capped.size else [])
+    report = {}
+    for kind, i in picks:
+        tr = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            rt, rL, rJ, rc, its = zo.differentialDynamicProgramming(fn, ft, Q, R, Qf, x0[i], ug[i], return_iters=True, trace=tr)
+        agree = _agreement(Jtr[:, i], atr[:, i], tr)
+        report[kind] = (i, agree, its, float(J[i]), float(rJ))
+        assert rc == bool(conv[i]), (kind, i)
+        assert agree >= min(10, its), (kind, i, agree, its)
+        if rc:
+            assert agree == its and J[i] == pytest.approx(rJ, rel=1e-9) and _rel(traj.uTraj[i], rt.uTraj) <= 1e-5
+    print("DDP vs oracle loop (index, iterations in agreement, oracle iterations, J kernel, J oracle):", report)
