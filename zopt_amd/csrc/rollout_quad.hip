@@ -125,10 +125,13 @@ __global__ __launch_bounds__(256) void rollout_quad_all_kernel(const QuadArgs g)
         for (int i = 0; i < QN; ++i) so[(i >> 1) * 32 + (i & 1)] = x[i];
     }
     double J = 0.0;
-    QuadOps oa, ob;
+    // operands TWO steps ahead in three rotating register sets: with ~1000 trajectories in flight the operands come from HBM, and one
+    // step of this chain (~0.8 us) is shorter than that round trip under load
+    QuadOps oa, ob, oc;
     quad_load(oa, Lr, xp, lq, upq, 0);
-    auto body = [&](const QuadOps& cur, QuadOps& nxt, const int k) {
-        if (k + 1 < T) quad_load(nxt, Lr, xp, lq, upq, k + 1);
+    if (T > 1) quad_load(ob, Lr, xp, lq, upq, 1);
+    auto body = [&](const QuadOps& cur, QuadOps& nxt2, const int k) {
+        if (k + 2 < T) quad_load(nxt2, Lr, xp, lq, upq, k + 2);
         quad_step<true>(cur, q, al, g.dt, qd, rd, x, u, J);
         if (st) {
             double* sb = so + (long)(k + 1) * Q_ALLSTORE_BLOCK;
@@ -139,11 +142,13 @@ __global__ __launch_bounds__(256) void rollout_quad_all_kernel(const QuadArgs g)
         }
     };
     int k = 0;
-    for (; k + 1 < T; k += 2) {   // ping-pong operand registers: no copies
-        body(oa, ob, k);
+    for (; k + 2 < T; k += 3) {   // rotating operand registers: no copies
+        body(oa, oc, k);
         body(ob, oa, k + 1);
+        body(oc, ob, k + 2);
     }
-    if (k < T) body(oa, ob, k);
+    if (k < T) body(oa, oc, k);
+    if (k + 1 < T) body(ob, oa, k + 1);
     {   // terminal cost, rollout_fast.hip's diagonal quad_form
         double jf = 0.0;
 #pragma unroll
@@ -199,10 +204,11 @@ __global__ __launch_bounds__(64) void rollout_quad_reroll_kernel(const QuadArgs 
         for (int i = 0; i < QN; ++i) xo[i] = x[i];
     }
     double J = 0.0;
-    QuadOps oa, ob;
+    QuadOps oa, ob, oc;   // operands two steps ahead, as in rollout_quad_all_kernel
     quad_load(oa, Lr, xp, lq, upq, 0);
-    auto body = [&](const QuadOps& cur, QuadOps& nxt, const int k) {
-        if (k + 1 < T) quad_load(nxt, Lr, xp, lq, upq, k + 1);
+    if (T > 1) quad_load(ob, Lr, xp, lq, upq, 1);
+    auto body = [&](const QuadOps& cur, QuadOps& nxt2, const int k) {
+        if (k + 2 < T) quad_load(nxt2, Lr, xp, lq, upq, k + 2);
         quad_step<false>(cur, q, al, g.dt, qd, rd, x, u, J);
         if (st) {
 #pragma unroll
@@ -212,11 +218,13 @@ __global__ __launch_bounds__(64) void rollout_quad_reroll_kernel(const QuadArgs 
         }
     };
     int k = 0;
-    for (; k + 1 < T; k += 2) {
-        body(oa, ob, k);
+    for (; k + 2 < T; k += 3) {
+        body(oa, oc, k);
         body(ob, oa, k + 1);
+        body(oc, ob, k + 2);
     }
-    if (k < T) body(oa, ob, k);
+    if (k < T) body(oa, oc, k);
+    if (k + 1 < T) body(ob, oa, k + 1);
 }
 
 // rollout_fast.hip decides when these apply (quadcopter in still air, diagonal weights asserted, 16 step sizes)
