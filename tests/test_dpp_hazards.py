@@ -1,9 +1,9 @@
 """CPU check of the generated gfx950 ISA: no VALU-write -> DPP-read hazard around the inline-asm DPP instructions.
 
-`v_fmac_f64_dpp` (mpc_wave.hip) and `v_fmac_f32_dpp` / `v_mul_f32_dpp` (lqr_tiled_core.h) are inline asm, and LLVM's hazard
+`v_fmac_f64_dpp` (mpc_wave.hip, rollout_fast.hip) and `v_fmac_f32_dpp` / `v_mul_f32_dpp` (lqr_tiled_core.h) are inline asm, and LLVM's hazard
 recognizer does not pad hazards around inline asm: the two wait states a DPP read of a VGPR needs after a VALU write of it come
 from a separate `asm("s_nop 1" : "+v"(v))` statement in the source.  Nothing in the compiler keeps a register-allocator copy
-(`v_mov`) from landing between the two statements, which would silently give wrong values.  So this test compiles the two
+(`v_mov`) from landing between the two statements, which would silently give wrong values.  So this test compiles the
 translation units to assembly (`hipcc --cuda-device-only -S`, no GPU needed) and checks, for every `*_dpp` instruction, that no
 VALU instruction wrote its DPP source operand within the previous two wait states (an instruction in between = 1 wait state,
 `s_nop N` = N + 1)."""
@@ -78,7 +78,7 @@ def test_scanner_sees_a_planted_hazard():
     assert scan(bad)[1] and scan(copy)[1]
 
 
-@pytest.mark.parametrize("src", ["mpc_wave.hip", "lqr_backward_tiled_f32.hip"])
+@pytest.mark.parametrize("src", ["mpc_wave.hip", "lqr_backward_tiled_f32.hip", "rollout_fast.hip"])
 def test_no_valu_write_to_dpp_read_hazard_in_generated_isa(src, tmp_path):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")

@@ -107,11 +107,60 @@ struct PolPtrs {
     int st[5];
 };
 
+// One step's policy data of a trajectory, spread over the 16 lanes that roll it out: element e of [l|L|xPrev|uPrev] sits in register
+// v[e >> 4] of lane e & 15 -- exactly where the cooperative load puts it.  Nobody gathers it: every use is an FMA whose DPP source
+// operand reads the owning lane (v_fmac_f64_dpp ... row_newbcast, the one DPP control 64-bit ALU instructions accept), so the data
+// never goes through LDS (round 2 staged it there: 45 LDS instructions and a wave barrier per step, 38 % of the wave's cycles in
+// s_waitcnt at two waves per SIMD -- profiles/r03_rollfast_pmc.txt).
+struct PolRegs {
+    double v[5];
+};
+// acc += c * (policy element E)
+template <int E>
+__device__ __forceinline__ void pol_fma(double& acc, const double c, const PolRegs& r) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(r.v[E >> 4]), "v"(c), "i"(E & 15));
+}
+// the two wait states a DPP read needs after a VALU write of its source (hipcc pads nothing inside asm): every step passes its five
+// registers through this once, the broadcasts depend on the statement and hence follow it
+__device__ __forceinline__ void pol_settle(PolRegs& r) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) asm("s_nop 1" : "+v"(r.v[i]));
+}
+// dx[j] = x[j] - xPrev_k[j]   as fma(-1, xPrev, x): one rounding of the same difference
+template <int J = 0>
+__device__ __forceinline__ void pol_dx(double (&dx)[RN], const double (&x)[RN], const double neg1, const PolRegs& r) {
+    if constexpr (J < RN) {
+        dx[J] = x[J];
+        pol_fma<RM + RM * RN + J>(dx[J], neg1, r);
+        pol_dx<J + 1>(dx, x, neg1, r);
+    }
+}
+// s += sum_j L_k[I][j] dx[j], j ascending
+template <int I, int J = 0>
+__device__ __forceinline__ void pol_row(double& s, const double (&dx)[RN], const PolRegs& r) {
+    if constexpr (J < RN) {
+        pol_fma<RM + I * RN + J>(s, dx[J], r);
+        pol_row<I, J + 1>(s, dx, r);
+    }
+}
+// u = (alpha * l_k + L_k (x - xPrev_k)) + uPrev_k            (pytrees.py:220, ilqrUtils.py:59-60)
+template <int I = 0>
+__device__ __forceinline__ void pol_controls(double (&u)[RM], const double (&dx)[RN], const double al, const double one, const PolRegs& r) {
+    if constexpr (I < RM) {
+        double s = 0.0;
+        pol_row<I>(s, dx, r);
+        pol_fma<I>(s, al, r);                           // fma(l_k[I], alpha, s)
+        pol_fma<RM + RM * RN + RN + I>(s, one, r);      // + uPrev_k[I]
+        u[I] = s;
+        pol_controls<I + 1>(u, dx, al, one, r);
+    }
+}
+
 template <int KIND, bool DIAG, bool ALL>
 // (no __restrict__ on the LDS tables: with it the loop-invariant LDS reads of Q, A, B ... are hoisted into registers --
 //  several hundred VGPRs -- instead of being re-read by broadcast every step)
 __device__ __forceinline__ void rollout_ls_body(const FastArgs& g, const double* Qs, const double* Rs, const double* Qfs,
-                                                const double* As, const double* Bs, double (*pol)[4][PSZ + 4]) {
+                                                const double* As, const double* Bs) {
     const int lane = threadIdx.x;
     const int grp = lane >> 4, a = lane & 15;
     const long slot = (long)blockIdx.x * 4 + grp;
@@ -156,7 +205,7 @@ __device__ __forceinline__ void rollout_ls_body(const FastArgs& g, const double*
 
     // one rollout of step size `al`; STORE: this lane writes xTraj / uTraj
     auto rollout = [&](const double al, const bool store) -> double {
-        double x[RN], u[RM], xn[RN], nx[5];
+        double x[RN], u[RM], xn[RN];
 #pragma unroll
         for (int i = 0; i < RN; ++i) x[i] = x0t[i];
         if (store) {
@@ -168,17 +217,6 @@ __device__ __forceinline__ void rollout_ls_body(const FastArgs& g, const double*
                 for (int i = 0; i < RN; ++i) xo[i] = x[i];
             }
         }
-        // stage step 0
-        {
-            double v0[5];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) v0[i] = *pp.p[i];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int e = a + 16 * i;
-                if (e < PSZ + 4) pol[0][grp][e] = v0[i];
-            }
-        }
         double J = 0.0;
         double qd[(ALL && DIAG) ? RN : 1], rd[(ALL && DIAG) ? RM : 1];
         if constexpr (ALL && DIAG) {
@@ -187,41 +225,19 @@ __device__ __forceinline__ void rollout_ls_body(const FastArgs& g, const double*
 #pragma unroll
             for (int j = 0; j < RM; ++j) rd[j] = Rs[j * RM + j];
         }
-        for (int k = 0; k < T; ++k) {
-            const int cur = k & 1;
-            const bool more = (k + 1 < T);
-            if (more) {
+        double one = 1.0, neg1 = -1.0;
+        asm("" : "+v"(one), "+v"(neg1));   // in registers: VOP2 DPP takes no literal
+        // the policy data of a step arrives three steps ahead, in four rotating register sets (five registers each)
+        auto fetch = [&](PolRegs& r, const int k) {
 #pragma unroll
-                for (int i = 0; i < 5; ++i) nx[i] = pp.p[i][(long)(k + 1) * pp.st[i]];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const double* pks = pol[cur][grp];
-            // All-store mode runs as a lone wave per SIMD with registers to spare: the step's 68 policy values are fetched from LDS
-            // in one batch and waited for once -- read where they are used, each of ~40 waits exposed part of an LDS round trip to
-            // the dependency chain.  (Same values, same arithmetic.)
-            double pkr[ALL ? PSZ : 1];
-            if constexpr (ALL) {
-#pragma unroll
-                for (int e = 0; e < PSZ; ++e) pkr[e] = pks[e];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            const double* pk = ALL ? pkr : pks;
-            // u = (alpha * l_k + L_k (x - xPrev_k)) + uPrev_k            (pytrees.py:220, ilqrUtils.py:59-60)
+            for (int i = 0; i < 5; ++i) r.v[i] = pp.p[i][(long)k * pp.st[i]];
+        };
+        auto body = [&](PolRegs& cur, PolRegs& ahead, const int k) {
+            if (k + 3 < T) fetch(ahead, k + 3);
+            pol_settle(cur);
             double dx[RN];
-#pragma unroll
-            for (int j = 0; j < RN; ++j) dx[j] = x[j] - pk[RM + RM * RN + j];
-#pragma unroll
-            for (int i = 0; i < RM; ++i) {
-                double s = 0.0;
-#pragma unroll
-                for (int j = 0; j < RN; ++j) s = __builtin_fma(pk[RM + i * RN + j], dx[j], s);
-                u[i] = (al * pk[i] + s) + pk[RM + RM * RN + RN + i];
-                // one row of L_k in flight at a time (registers: three waves per SIMD) -- except in all-store mode, which runs when
-                // the chip is nearly empty and a lone wave wants its four row chains interleaved
-                if constexpr (!ALL) __builtin_amdgcn_sched_barrier(0);
-            }
+            pol_dx(dx, x, neg1, cur);
+            pol_controls(u, dx, al, one, cur);
             if constexpr (ALL && DIAG) {   // the diagonal weights from registers (loaded before the loop); quad_form's arithmetic
                 double jx = 0.0, ju = 0.0;
 #pragma unroll
@@ -249,13 +265,16 @@ __device__ __forceinline__ void rollout_ls_body(const FastArgs& g, const double*
                     for (int i = 0; i < RN; ++i) xo[(long)(k + 1) * RN + i] = x[i];
                 }
             }
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    const int e = a + 16 * i;
-                    if (e < PSZ + 4) pol[cur ^ 1][grp][e] = nx[i];
-                }
-            }
+        };
+        PolRegs pa, pb, pc, pd;
+        fetch(pa, 0);
+        if (T > 1) fetch(pb, 1);
+        if (T > 2) fetch(pc, 2);
+        for (int k = 0; k < T; k += 4) {   // rotating sets: no copies
+            body(pa, pd, k);
+            if (k + 1 < T) body(pb, pa, k + 1);
+            if (k + 2 < T) body(pc, pb, k + 2);
+            if (k + 3 < T) body(pd, pc, k + 3);
         }
         J += quad_form<DIAG, RN>(Qfs, x);
         return J;
@@ -301,7 +320,6 @@ template <int KIND, bool DIAG_ONLY, bool ALL>
 __global__ __launch_bounds__(64) void rollout_ls_fast_kernel(const FastArgs g) {
     __shared__ double Qs[RN * RN], Rs[RM * RM], Qfs[RN * RN];
     __shared__ double As[KIND == ZM_MODEL_LINEAR ? RN * RN : 1], Bs[KIND == ZM_MODEL_LINEAR ? RN * RM : 1];
-    __shared__ double pol[2][4][PSZ + 4];
     const int lane = threadIdx.x;
     bool offdiag = false;
     for (int e = lane; e < RN * RN; e += 64) {
@@ -321,13 +339,13 @@ __global__ __launch_bounds__(64) void rollout_ls_fast_kernel(const FastArgs g) {
     }
     __syncthreads();
     if constexpr (DIAG_ONLY) {
-        rollout_ls_body<KIND, true, ALL>(g, Qs, Rs, Qfs, As, Bs, pol);
+        rollout_ls_body<KIND, true, ALL>(g, Qs, Rs, Qfs, As, Bs);
     } else {
         // diagonal weights (the demos' Q = I, R = I, Qf = 10 I): x^T W x costs n FMAs instead of n^2; wave-uniform
         if (__ballot(offdiag) == 0ull)
-            rollout_ls_body<KIND, true, ALL>(g, Qs, Rs, Qfs, As, Bs, pol);
+            rollout_ls_body<KIND, true, ALL>(g, Qs, Rs, Qfs, As, Bs);
         else
-            rollout_ls_body<KIND, false, ALL>(g, Qs, Rs, Qfs, As, Bs, pol);
+            rollout_ls_body<KIND, false, ALL>(g, Qs, Rs, Qfs, As, Bs);
     }
 }
 

@@ -67,7 +67,7 @@ __device__ __forceinline__ void quad_step(const QuadOps& o, const int q, const d
     double s = 0.0;
 #pragma unroll
     for (int j = 0; j < QN; ++j) s = __builtin_fma(o.Lq[j], dx[j], s);
-    const double uq = (al * o.lq + s) + o.upq;
+    const double uq = __builtin_fma(al, o.lq, s) + o.upq;   // (explicit: the same contraction as rollout_fast.hip's DPP form)
     u[0] = quad_bcast<0>(uq);
     u[1] = quad_bcast<1>(uq);
     u[2] = quad_bcast<2>(uq);

@@ -11,6 +11,7 @@
 namespace zm {
 
 __device__ __forceinline__ void zm_sincos(const double x, double* sn, double* cs) {
+#pragma clang fp contract(off)   // every FMA below is explicit: the same bits in whichever kernel this is inlined (see quad_step.h)
 #ifdef ZM_LIBM_SINCOS   // A/B builds: the library everywhere
     sincos(x, sn, cs);
     return;
@@ -33,7 +34,7 @@ __device__ __forceinline__ void zm_sincos(const double x, double* sn, double* cs
     pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
     pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
     const double hz = 0.5 * z, w = 1.0 - hz;
-    const double c = w + (((1.0 - w) - hz) + (z * z) * pc);
+    const double c = w + __builtin_fma(z * z, pc, (1.0 - w) - hz);
     // quadrant k mod 4:  0: (s, c)   1: (c, -s)   2: (-s, -c)   3: (-c, s)
     const int q = (int)__builtin_fma(-4.0, __builtin_rint(0.25 * k), k);   // k mod 4 in {-2..2}, no integer overflow for huge k
     const double s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
