@@ -157,3 +157,20 @@ def test_ilqr_workspace_omits_the_all_store_scratch_where_the_line_search_cannot
         b = lib.zm_ilqr_solve_workspace_f64(ctypes.addressof(windy), batch, T, 0)
         assert a > 0 and b > 0
         assert a - b == min(batch, 2048) * (T + 1) * 256
+
+
+def test_lqrMpc_constructor_refuses_what_cvxpy_refuses():
+    """host logic, no GPU: inconsistent shapes and weights that are not positive semidefinite (the reference's cvxpy problem is then
+    not DCP and `solve` raises; mpcUtils.py:49-59) are refused when the problem is built; a singular PSD weight is accepted"""
+    import numpy as np
+    import pytest
+    from zopt_amd import mpcUtils
+    A, B = np.eye(2), np.ones((2, 1))
+    lb, ub = -np.ones(2), np.ones(2)
+    mpcUtils.lqrMpc(A, B, np.diag([1.0, 0.0]), np.zeros((1, 1)), 3, lb, ub, -np.ones(1), np.ones(1))          # PSD, singular: fine
+    with pytest.raises(ValueError, match="not positive semidefinite"):
+        mpcUtils.lqrMpc(A, B, np.diag([1.0, -0.1]), np.eye(1), 3, lb, ub, -np.ones(1), np.ones(1))
+    with pytest.raises(ValueError, match="Qf is not positive semidefinite"):
+        mpcUtils.lqrMpc(A, B, np.eye(2), np.eye(1), 3, lb, ub, -np.ones(1), np.ones(1), Qf=np.array([[0.0, 1.0], [1.0, 0.0]]))
+    with pytest.raises(ValueError, match="shapes"):
+        mpcUtils.lqrMpc(A, B, np.eye(3), np.eye(1), 3, lb, ub, -np.ones(1), np.ones(1))

@@ -52,6 +52,13 @@ class lqrMpc():
         if self.A.shape != (self.n, self.n) or self.Q.shape != (self.n, self.n) or self.R.shape != (self.m, self.m) \
                 or self.x_lb.shape != (self.n,) or self.u_lb.shape != (self.m,) or self.N < 1:
             raise ValueError("inconsistent lqrMpc problem shapes")
+        # cvxpy refuses the reference's problem (DCPError at solve time) unless every quad_form weight is positive semidefinite; here the
+        # ADMM's Hessians 2Q + rho I would hide a slightly indefinite weight and return the stationary point of a non-convex problem
+        for name, W in (("Q", self.Q), ("R", self.R), ("Qf", self.Qf)):
+            w = np.linalg.eigvalsh(0.5 * (W + W.T))
+            if w[0] < -1e-10 * max(1.0, abs(w[-1])):
+                raise ValueError(f"lqrMpc: {name} is not positive semidefinite (smallest eigenvalue {w[0]:.3g}): the problem is not "
+                                 f"convex (cvxpy raises DCPError for the reference's quad_form)")
         self._dev = None
         self._tables = {}
         self._ws = None   # ((batch, device, rho), ADMM workspace) of the last solve: warm start
