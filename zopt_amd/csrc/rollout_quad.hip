@@ -1,8 +1,8 @@
 // K6-Q  the quadcopter's rollouts on FOUR lanes per (trajectory, step size) -- gfx950.
 //
 // Same arithmetic, bit for bit, as rollout_fast.hip (reference ilqrUtils.py:33-66, 116-150; pytrees.py:49-52, 215-220); what changes
-// is who computes it.  A rollout is a chain of T dependent steps of ~310 VALU instructions per lane, and a lone wave issues an fp64
-// instruction only every 6-8 cycles: when few waves are in flight, the launch lasts as long as that chain.  Here the lanes of a quad
+// is who computes it.  A rollout is a chain of T dependent steps of ~310 VALU instructions per lane, and a lone wave issues dependent fp64
+// instructions only every ~9.5 cycles (independent ones every 4.7): when few waves are in flight, the launch lasts as long as that chain.  Here the lanes of a quad
 // share one rollout: lane q computes row q of the policy product L_k (x - xPrev_k) and the sine / cosine of one Euler angle, and
 // loads only what it needs (row q of L_k, xPrev_k, l_k[q], uPrev_k[q]: 26 doubles instead of 68) straight from global memory, one
 // step ahead, in registers; controls and trigonometric values are exchanged by DPP quad broadcasts.  Dynamics, cost and state update
