@@ -915,7 +915,7 @@ int sweep_packed_jacobians(const double* Fp, int njp, const unsigned char* pos, 
     // few trajectories left (at most one wave per SIMD): four-wave workgroups, one wave per SIMD of a CU
     static const long wg4_max = [] {   // ZOPT_AMD_SWEEP_WG4=<n>: four-wave workgroups up to n listed trajectories (A/B)
         const char* e = zm::lab_env("ZOPT_AMD_SWEEP_WG4");
-        return e ? atol(e) : 1024L;
+        return e ? atol(e) : 2048L;   // (round 3, same-box A/B of the 8192-problem solve: 34.8-34.9 ms at 1024, 34.3-34.5 at 2048, 34.2-34.7 at 3072 / 4096)
     }();
     const bool quad_wg = tl.list && nslot <= wg4_max;
     const dim3 grid((unsigned)(quad_wg ? (nslot + 3) / 4 : nslot)), block(quad_wg ? 256 : 64);
