@@ -238,7 +238,7 @@ def test_diagonal_weight_kernels_agree(mods, kind):
         assert _rel(traj.xTraj[b], rt.xTraj) <= 1e-9 and _rel(traj.uTraj[b], rt.uTraj) <= 1e-9
 
 
-@pytest.mark.parametrize("N", [1, 2, 9, 30])
+@pytest.mark.parametrize("N", [1, 2, 3, 7, 9, 30])     # every remainder of the kernels' three- and four-step loop bodies
 def test_reroll_as_its_own_launch_matches_the_second_pass(mods, N):
     """zm_rollout_linesearch_list_f64 with an alpha_idx buffer re-rolls the winners in rollout_quad_reroll_kernel (four lanes per
     rollout, 16 trajectories per wave); without one the second pass runs inside the line-search kernel.  Same bits, same winners,
