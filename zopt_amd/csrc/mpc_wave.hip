@@ -2,14 +2,14 @@
 //
 // Same algorithm, same termination and certificate as mpc_solve_kernel (mpc.hip; problem: zopt/mpcUtils.py:48-59): only
 // the mapping differs.  One lane per instance leaves an MI355X nearly idle at the batch sizes MPC is used with (1024
-// instances = 16 waves) and makes every ADMM iteration a chain of 60 x ~500 dependent FMAs in one lane.  Here lane i of a
-// 16-lane group holds component i of the state-sized vectors (lanes 0..m-1 also the control-sized ones) and ROW / COLUMN i
-// of A, B, K_k, Suu_k^-1; a mat-vec is NL broadcasts (DPP row_newbcast, no LDS) + NL FMAs per lane:
-//     backward stage:  p = p' - rho z_x;  [Qu | A^T p] in one pass over p;  [kf | K^T Qu] in one pass over Qu
-//     forward  stage:  [K x | A x] in one pass over x;  + B u;  clip / dual update on the lane's own components
-// ~160 instructions per stage instead of ~1000.  The iterates y, lam, kf (and the certificate's r) live in LDS, one private
+// instances = 16 waves) and makes every ADMM iteration a chain of 60 x ~500 dependent FMAs in one lane.  Here the 16 lanes of a
+// group carry the STACKED index [x ; u]: lane i < n holds state component i, lane n + j control component j, each with its row / column
+// of A, B, K_k, Suu_k^-1; a mat-vec is NL broadcasts (DPP row_newbcast, no LDS) + NL FMAs per lane, and it serves both blocks at once:
+//     backward stage:  p = p' - rho z_x;  [A^T p ; Qu = -rho z_u + B^T p] in one pass over p;  [K^T Qu ; kf] in one pass over Qu
+//     forward  stage:  [A x ; K x] in one pass over x;  + B u;  clip / dual update once, on the stacked iterate
+// ~75 vector instructions per stage pair.  The iterates y, lam, kf (and the certificate's r) live in LDS, one private
 // slot per lane and stage: no cross-lane LDS traffic, hence no barrier anywhere in the loop; HBM is touched only for the
-// tables K_k, Suu_k^-1 (L2-resident, fetched one stage ahead) and at entry / exit (warm start, results).
+// tables K_k, Suu_k^-1 (L2-resident, fetched three stages ahead) and at entry / exit (warm start, results).
 #include "mpc_common.h"
 
 #include <hip/hip_runtime.h>
@@ -32,45 +32,42 @@ __device__ __forceinline__ double dpp_src(double v) {
 // a1 += sum_l c1[l] v_l,  a2 += sum_l c2[l] v_l   over the first NL lanes of the row.  The sums run as PS interleaved partial
 // chains (term l goes to chain l % PS): a single chain of 12 dependent FMAs is the longest dependency of a stage, and the
 // solve is the latency of 60 such stages per ADMM iteration.
-template <int NL, int PS, int L = 0>
-__device__ __forceinline__ void mv2_acc(const double (&c1)[NL], const double (&c2)[NL], const double v, double (&s1)[PS],
-                                        double (&s2)[PS]) {
+// acc += sum_l c[l] v_(OFF + l): the vector's components sit in lanes OFF .. OFF + NL - 1 of the row.  The sums run as PS interleaved
+// partial chains (term l goes to chain l % PS; chain 0 starts from acc): a single chain of 12 dependent FMAs would be the longest
+// dependency of a stage.
+template <int NL, int PS, int OFF, int L = 0>
+__device__ __forceinline__ void mv_acc(const double (&c)[NL], const double v, double (&s)[PS]) {
     if constexpr (L < NL) {
-        fma_bc<L>(s1[L % PS], c1[L], v);
-        fma_bc<L>(s2[L % PS], c2[L], v);
-        mv2_acc<NL, PS, L + 1>(c1, c2, v, s1, s2);
+        fma_bc<OFF + L>(s[L % PS], c[L], v);
+        mv_acc<NL, PS, OFF, L + 1>(c, v, s);
     }
 }
-template <int NL>
-__device__ __forceinline__ void mv2(const double (&c1)[NL], const double (&c2)[NL], const double v, double& a1, double& a2) {
+template <int NL, int OFF = 0>
+__device__ __forceinline__ void mv(const double (&c)[NL], const double v, double& a) {
     constexpr int PS = NL >= 9 ? 3 : (NL >= 4 ? 2 : 1);
-    double s1[PS], s2[PS];
-    s1[0] = a1;
-    s2[0] = a2;
+    double s[PS];
+    s[0] = a;
 #pragma unroll
-    for (int i = 1; i < PS; ++i) s1[i] = s2[i] = 0.0;
-    mv2_acc<NL, PS>(c1, c2, dpp_src(v), s1, s2);
-    if constexpr (PS == 3) {
-        a1 = (s1[0] + s1[1]) + s1[2];
-        a2 = (s2[0] + s2[1]) + s2[2];
-    } else if constexpr (PS == 2) {
-        a1 = s1[0] + s1[1];
-        a2 = s2[0] + s2[1];
-    } else {
-        a1 = s1[0];
-        a2 = s2[0];
-    }
+    for (int i = 1; i < PS; ++i) s[i] = 0.0;
+    mv_acc<NL, PS, OFF>(c, dpp_src(v), s);
+    if constexpr (PS == 3)
+        a = (s[0] + s[1]) + s[2];
+    else if constexpr (PS == 2)
+        a = s[0] + s[1];
+    else
+        a = s[0];
 }
-template <int NL, int L = 0>
-__device__ __forceinline__ void mv1_acc(const double (&c1)[NL], const double v, double& a1) {
+// the same as ONE chain (the short products onto an accumulator that is itself the end of a chain)
+template <int NL, int OFF, int L = 0>
+__device__ __forceinline__ void mv_seq_acc(const double (&c)[NL], const double v, double& a) {
     if constexpr (L < NL) {
-        fma_bc<L>(a1, c1[L], v);
-        mv1_acc<NL, L + 1>(c1, v, a1);
+        fma_bc<OFF + L>(a, c[L], v);
+        mv_seq_acc<NL, OFF, L + 1>(c, v, a);
     }
 }
-template <int NL>
-__device__ __forceinline__ void mv1(const double (&c1)[NL], const double v, double& a1) {
-    mv1_acc<NL>(c1, dpp_src(v), a1);
+template <int NL, int OFF>
+__device__ __forceinline__ void mv_seq(const double (&c)[NL], const double v, double& a) {
+    mv_seq_acc<NL, OFF>(c, dpp_src(v), a);
 }
 __device__ __forceinline__ double row_max(double v) {
 #pragma unroll
@@ -83,15 +80,22 @@ __device__ __forceinline__ double row_sum(double v) {
     return v;
 }
 
-// LDS per group and stage (doubles): yx[16] lx[16] rx[16] | yu[4] lu[4] ru[4] kf[4]
+// LDS per group and stage (doubles): y[16] lam[16] r[16] kf[16], one slot per lane
 constexpr int WS_STAGE = 64;
 
+// Lane roles (round 3): the STACKED index [x ; u] on the 16 lanes of a group -- lane i < NS owns state component i, lane NS + j owns
+// control component j (NS + MC <= 16 for every compiled shape).  A mat-vec over the state lanes then serves both blocks of its result in
+// ONE FMA per broadcast, each lane with its own coefficients ([A^T p ; B^T p], [A x ; K x]), and the projection / dual update runs once
+// for the stacked iterate -- rounds 1-2 kept the control components in lanes 0 .. MC-1 next to the states, which cost two FMAs per
+// broadcast and a second, four-lane copy of the update (~120 vector instructions per stage pair instead of ~75).  Same sums in the same
+// order: the iterates are bit for bit those of the older mapping.
 template <int NS, int MC>
 __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __restrict__ A, const double* __restrict__ B,
                                                             const double* __restrict__ Ktab, const double* __restrict__ Mtab,
                                                             const double* __restrict__ x_lb, const double* __restrict__ x_ub,
                                                             const double* __restrict__ u_lb, const double* __restrict__ u_ub,
                                                             const MpcArgs g) {
+    static_assert(NS + MC <= 16, "the stacked index must fit the 16 lanes of a group");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int W = NS + MC;
     const int lane = threadIdx.x, grp = lane >> 4, li = lane & 15;
@@ -101,36 +105,31 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
     const int N = g.N;
     double rho = g.rho;        // penalty of this group (changes with adaptive levels)
     int lvl = g.level0;
-    const bool sx = li < NS, su = li < MC;         // this lane owns a state / a control component
-    const int ix = sx ? li : 0, iu = su ? li : 0;
+    const bool sx = li < NS, su = (li >= NS) && (li < W), sw = li < W;   // this lane owns a state / a control / any component
+    const int ix = sx ? li : 0, iu = su ? li - NS : 0, iw = sw ? li : 0;
     double* base = lds + (long)grp * N * WS_STAGE;
-    double* yx = base + li;                        // + k * WS_STAGE
-    double* lx = base + 16 + li;
-    double* rx = base + 32 + li;
-    double* yu = base + 48 + iu;
-    double* lu = base + 52 + iu;
-    double* ru = base + 56 + iu;
-    double* kf = base + 60 + iu;
+    double* yw = base + li;                        // + k * WS_STAGE
+    double* lw = base + 16 + li;
+    double* rw = base + 32 + li;
+    double* kf = base + 48 + li;                   // (control lanes)
 
-    // rows / columns of the shared matrices (zero outside the lane's role)
-    double Arow[NS], Acol[NS], Bcol[NS], Brow[MC];
+    // the lane's column of [A | B] (the adjoint products over the state lanes) and its row of B (zero outside the state lanes)
+    double ABcol[NS], Brow[MC];
 #pragma unroll
     for (int l = 0; l < NS; ++l) {
-        const double ar = A[ix * NS + l], ac = A[l * NS + ix], bcv = B[l * MC + iu];
-        Arow[l] = sx ? ar : 0.0;
-        Acol[l] = sx ? ac : 0.0;
-        Bcol[l] = su ? bcv : 0.0;
+        const double ac = A[l * NS + ix], bc = B[l * MC + iu];
+        ABcol[l] = sx ? ac : (su ? bc : 0.0);
     }
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
         const double br = B[ix * MC + j];
         Brow[j] = sx ? br : 0.0;
     }
-    const double xlo = sx ? x_lb[ix] : -__builtin_inf(), xhi = sx ? x_ub[ix] : __builtin_inf();
-    const double ulo = su ? u_lb[iu] : -__builtin_inf(), uhi = su ? u_ub[iu] : __builtin_inf();
+    const double inf = __builtin_inf();
+    const double lo = sx ? x_lb[ix] : (su ? u_lb[iu] : -inf), hi = sx ? x_ub[ix] : (su ? u_ub[iu] : inf);
     const double x0 = sx ? g.x0[inst * NS + ix] : 0.0;
     // x_0 = x0 is box-constrained too (mpcUtils.py:56,58): group-wide AND over the state lanes
-    const double viol = (sx && !(x0 >= xlo && x0 <= xhi)) ? 1.0 : 0.0;
+    const double viol = (sx && !(x0 >= lo && x0 <= hi)) ? 1.0 : 0.0;
     const bool x0_in = row_max(viol) == 0.0;
 
     // per-instance block of the caller's workspace: [y (N,W) | lam (N,W) | kf (N,MC), ok flag, spare | unused]
@@ -146,44 +145,38 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
     }
     for (int k = 0; k < N; ++k) {
         const int ks = (g.warm == 2 && k + 1 < N) ? k + 1 : k;    // shifted warm start: iterate k <- iterate k+1
-        const double wyx = warm ? wsi[(long)ks * W + ix] : 0.0, wlx = warm ? wsi[(long)N * W + (long)ks * W + ix] : 0.0;
-        const double wyu = warm ? wsi[(long)ks * W + NS + iu] : 0.0, wlu = warm ? wsi[(long)N * W + (long)ks * W + NS + iu] : 0.0;
-        yx[k * WS_STAGE] = sx ? wyx : 0.0;
-        lx[k * WS_STAGE] = sx ? wlx : 0.0;
-        rx[k * WS_STAGE] = 0.0;
-        if (su) {
-            yu[k * WS_STAGE] = wyu;
-            lu[k * WS_STAGE] = wlu;
-            ru[k * WS_STAGE] = 0.0;
-            kf[k * WS_STAGE] = 0.0;
-        }
+        const double wy = warm ? wsi[(long)ks * W + iw] : 0.0, wl = warm ? wsi[(long)N * W + (long)ks * W + iw] : 0.0;
+        yw[k * WS_STAGE] = sw ? wy : 0.0;
+        lw[k * WS_STAGE] = sw ? wl : 0.0;
+        rw[k * WS_STAGE] = 0.0;
+        kf[k * WS_STAGE] = 0.0;
     }
 
-    // Table rows / columns of one stage: K row (control lanes), K column (state lanes), Suu^-1 row (control lanes).  No masking:
-    // a lane outside the role loads the finite entries of row / column 0 and computes a finite value nobody reads (only lanes
-    // < MC of qu / kf / u and lanes < NS of p / x are ever broadcast or stored).  Stage indices are clamped into [0, N).
-    // ... and with them the lane's own iterates of that stage from LDS (y, lam, kf: stage-local, so reading them stages ahead of
-    // their use is safe in both sweeps): no LDS round trip at the head of a stage's dependency chain.
+    // Table slices of one stage, by lane role, and the lane's own iterates of that stage from LDS (y, lam, kf: stage-local, so reading
+    // them stages ahead of their use is safe in both sweeps: no LDS round trip at the head of a stage's dependency chain):
+    //     fwd[l]  the lane's row of [A ; K_k]          (state lanes: row of A, re-read from L2 like the others; control lanes: row of K_k)
+    //     adj[j]  the lane's row of [K_k^T ; Suu_k^-1]  (state lanes: column of K_k; control lanes: row of Suu_k^-1)
+    // No masking: a lane outside every role (shapes with NS + MC < 16) loads the finite entries of row / column 0 and computes finite
+    // values nobody reads -- only lanes < NS of p / x and lanes NS .. W-1 of qu / u are ever broadcast, only lanes < W are stored or
+    // enter a norm.  Stage indices are clamped into [0, N).
     struct Tab {
-        double Krow[NS], Kcol[MC], Mrow[MC];
-        double yx, lx, yu, lu, kf;
+        double fwd[NS], adj[MC];
+        double y, lam, kf;
     };
     auto load_tab = [&](int k, Tab& t) {
         k = k < 0 ? 0 : (k >= N ? N - 1 : k);
-        t.yx = yx[k * WS_STAGE];
-        t.lx = lx[k * WS_STAGE];
-        t.yu = yu[k * WS_STAGE];
-        t.lu = lu[k * WS_STAGE];
+        t.y = yw[k * WS_STAGE];
+        t.lam = lw[k * WS_STAGE];
         t.kf = kf[k * WS_STAGE];
         const double* Kk = Ktab + ((long)lvl * N + k) * MC * NS;
         const double* Mk = Mtab + ((long)lvl * N + k) * MC * MC;
+        const double* pf = su ? Kk + iu * NS : A + ix * NS;
+        const double* pa = su ? Mk + iu * MC : Kk + ix;
+        const int sa = su ? 1 : NS;
 #pragma unroll
-        for (int i = 0; i < NS; ++i) t.Krow[i] = Kk[iu * NS + i];
+        for (int i = 0; i < NS; ++i) t.fwd[i] = pf[i];
 #pragma unroll
-        for (int j = 0; j < MC; ++j) {
-            t.Kcol[j] = Kk[j * NS + ix];
-            t.Mrow[j] = Mk[iu * MC + j];
-        }
+        for (int j = 0; j < MC; ++j) t.adj[j] = pa[j * sa];
     };
 
     const double alpha = g.alpha, om_alpha = 1.0 - g.alpha;
@@ -197,19 +190,18 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
         const bool chk = ((gi + 1) % ZM_MPC_CHK) == 0;
         // ---- backward affine sweep.  The table slices come from L2 (~500+ cycles) and a stage is shorter than that, so they are
         //      fetched THREE stages ahead into a rotating set of registers (the loop is unrolled by three: no copies).
-        double pp = 0.0;   // (A^T p - K^T Qu) of the stage above
+        double pp = 0.0;   // (A^T p - K^T Qu) of the stage above (state lanes)
         {
             auto bstage = [&](const int k, const Tab& t) {
-                const double zx = -rho * (t.yx - t.lx);
-                const double zu = su ? -rho * (t.yu - t.lu) : 0.0;
+                const double z = -rho * (t.y - t.lam);    // -rho z_x (state lanes), -rho z_u (control lanes)
                 const double kfo = t.kf;
-                const double p = pp + zx;             // costate of x_{k+1}
-                double qu = zu, pa = 0.0;
-                mv2<NS>(Bcol, Acol, p, qu, pa);       // Qu = -rho z_u + B^T p (control lanes);  A^T p (state lanes)
-                double kfv = 0.0, pk = 0.0;
-                mv2<MC>(t.Mrow, t.Kcol, qu, kfv, pk); // kf = Suu^-1 Qu;  K^T Qu
-                if (su) kf[k * WS_STAGE] = done ? kfo : kfv;
-                pp = pa - pk;
+                const double p = pp + z;                  // costate of x_{k+1} (state lanes)
+                double q = sx ? 0.0 : z;
+                mv<NS>(ABcol, p, q);                      // A^T p (state lanes);  Qu = -rho z_u + B^T p (control lanes)
+                double r = 0.0;
+                mv<MC, NS>(t.adj, q, r);                  // K^T Qu (state lanes);  kf = Suu^-1 Qu (control lanes)
+                if (su) kf[k * WS_STAGE] = done ? kfo : r;
+                pp = q - r;
             };
             Tab t0, t1, t2;
             load_tab(N - 1, t0);
@@ -233,47 +225,28 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
         double nrp = 0.0, nrd = 0.0, nw = 0.0, ny = 0.0, nl = 0.0, sup = 0.0, ndl = 0.0;
         {
             auto fstage = [&](const int k, const Tab& t) {
-                double ku = 0.0, xn = 0.0;
-                mv2<NS>(t.Krow, Arow, x, ku, xn);     // K x (control lanes), A x (state lanes)
-                const double u = su ? -t.kf - ku : 0.0;
-                mv1<MC>(Brow, u, xn);                 // + B u
-                {   // state component
-                    const double lold = t.lx, yold = t.yx;
-                    const double xh = __builtin_fma(alpha, xn, om_alpha * yold);   // relaxed iterate (alpha = 1: xn exactly)
-                    double yn = xh + lold;
-                    yn = yn < xlo ? xlo : (yn > xhi ? xhi : yn);
-                    const double r = xn - yn, dl = xh - yn, ln = lold + dl;        // primal residual; dual step
-                    yx[k * WS_STAGE] = (done || !sx) ? yold : yn;
-                    lx[k * WS_STAGE] = (done || !sx) ? lold : ln;
-                    if (chk) rx[k * WS_STAGE] = sx ? dl : 0.0;
-                    if (sx) {
-                        if (chk) {
-                            sup += (dl > 0.0) ? dl * xhi : ((dl < 0.0) ? dl * xlo : 0.0);
-                            ndl = __builtin_fmax(ndl, __builtin_fabs(dl));
-                        }
-                        nrp = __builtin_fmax(nrp, __builtin_fabs(r));
-                        nrd = __builtin_fmax(nrd, __builtin_fabs(yn - yold));
-                        nw = __builtin_fmax(nw, __builtin_fabs(xn));
-                        ny = __builtin_fmax(ny, __builtin_fabs(yn));
-                        nl = __builtin_fmax(nl, __builtin_fabs(ln));
-                    }
-                }
-                if (su) {   // control component
-                    const double lold = t.lu, yold = t.yu;
-                    const double uh = __builtin_fma(alpha, u, om_alpha * yold);
-                    double yn = uh + lold;
-                    yn = yn < ulo ? ulo : (yn > uhi ? uhi : yn);
-                    const double r = u - yn, dl = uh - yn, ln = lold + dl;
-                    yu[k * WS_STAGE] = done ? yold : yn;
-                    lu[k * WS_STAGE] = done ? lold : ln;
+                double ax = 0.0;
+                mv<NS>(t.fwd, x, ax);                 // A x (state lanes), K x (control lanes)
+                const double u = su ? -t.kf - ax : 0.0;
+                double xn = ax;
+                mv_seq<MC, NS>(Brow, u, xn);          // + B u (state lanes)
+                const double w = sx ? xn : u;         // the stacked iterate [x_{k+1} ; u_k]
+                const double lold = t.lam, yold = t.y;
+                const double wh = __builtin_fma(alpha, w, om_alpha * yold);   // relaxed iterate (alpha = 1: w exactly)
+                double yn = wh + lold;
+                yn = yn < lo ? lo : (yn > hi ? hi : yn);
+                const double r = w - yn, dl = wh - yn, ln = lold + dl;        // primal residual; dual step
+                yw[k * WS_STAGE] = (done || !sw) ? yold : yn;
+                lw[k * WS_STAGE] = (done || !sw) ? lold : ln;
+                if (chk) rw[k * WS_STAGE] = sw ? dl : 0.0;
+                if (sw) {
                     if (chk) {
-                        ru[k * WS_STAGE] = dl;
-                        sup += (dl > 0.0) ? dl * uhi : ((dl < 0.0) ? dl * ulo : 0.0);
+                        sup += (dl > 0.0) ? dl * hi : ((dl < 0.0) ? dl * lo : 0.0);
                         ndl = __builtin_fmax(ndl, __builtin_fabs(dl));
                     }
                     nrp = __builtin_fmax(nrp, __builtin_fabs(r));
                     nrd = __builtin_fmax(nrd, __builtin_fabs(yn - yold));
-                    nw = __builtin_fmax(nw, __builtin_fabs(u));
+                    nw = __builtin_fmax(nw, __builtin_fabs(w));
                     ny = __builtin_fmax(ny, __builtin_fabs(yn));
                     nl = __builtin_fmax(nl, __builtin_fabs(ln));
                 }
@@ -334,10 +307,7 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
             if (nl_ != lvl) {
                 const double rnew = g.rho * pow(g.rho_step, (double)(nl_ - g.level0));
                 const double sc = rho / rnew;
-                for (int k = 0; k < N; ++k) {
-                    lx[k * WS_STAGE] *= sc;
-                    if (su) lu[k * WS_STAGE] *= sc;
-                }
+                for (int k = 0; k < N; ++k) lw[k * WS_STAGE] *= sc;
                 rho = rnew;
                 lvl = nl_;
             }
@@ -345,15 +315,15 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
         // ---- primal infeasibility certificate (mpc.hip header): adjoint sweep over r = w - y
         if (chk && __any(need_cert)) {
             sup = row_sum(sup);
-            double sv = rx[(N - 1) * WS_STAGE];
+            double sv = sx ? rw[(N - 1) * WS_STAGE] : 0.0;
             double gmax = 0.0;
 #pragma unroll 1
             for (int k = N - 1; k >= 0; --k) {
-                double gv = su ? ru[k * WS_STAGE] : 0.0;
-                double sn = (k >= 1) ? rx[(k - 1) * WS_STAGE] : 0.0;
-                mv2<NS>(Bcol, Acol, sv, gv, sn);      // (G^T r)_k = r_u,k + B^T s;   s <- r_x,k-1 + A^T s
-                if (su) gmax = __builtin_fmax(gmax, __builtin_fabs(gv));
-                sv = sx ? sn : 0.0;
+                const double rk = rw[k * WS_STAGE], rkm = (k >= 1) ? rw[(k - 1) * WS_STAGE] : 0.0;
+                double gs = su ? rk : (sx ? rkm : 0.0);
+                mv<NS>(ABcol, sv, gs);                // (G^T r)_k = r_u,k + B^T s (control lanes);   s <- r_x,k-1 + A^T s (state lanes)
+                if (su) gmax = __builtin_fmax(gmax, __builtin_fabs(gs));
+                sv = sx ? gs : 0.0;
             }
             gmax = row_max(gmax);
             const double vw0 = row_sum(sv * x0);
@@ -372,20 +342,17 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
 #pragma unroll 1
         for (int k = 0; k < N; ++k) {
             load_tab(k, tf);
-            double ku = 0.0, xn = 0.0;
-            mv2<NS>(tf.Krow, Arow, x, ku, xn);
-            const double u = su ? -kf[k * WS_STAGE] - ku : 0.0;
-            mv1<MC>(Brow, u, xn);
+            double ax = 0.0;
+            mv<NS>(tf.fwd, x, ax);
+            const double u = su ? -kf[k * WS_STAGE] - ax : 0.0;
+            double xn = ax;
+            mv_seq<MC, NS>(Brow, u, xn);
             if (su) g.uTraj[(inst * N + k) * MC + iu] = u;
             x = sx ? xn : 0.0;
             if (sx) g.xTraj[(inst * (N + 1) + k + 1) * NS + ix] = x;
-            if (sx) {
-                wsi[(long)k * W + ix] = yx[k * WS_STAGE];
-                wsi[(long)N * W + (long)k * W + ix] = lx[k * WS_STAGE];
-            }
-            if (su) {
-                wsi[(long)k * W + NS + iu] = yu[k * WS_STAGE];
-                wsi[(long)N * W + (long)k * W + NS + iu] = lu[k * WS_STAGE];
+            if (sw) {
+                wsi[(long)k * W + iw] = yw[k * WS_STAGE];
+                wsi[(long)N * W + (long)k * W + iw] = lw[k * WS_STAGE];
             }
         }
         if (li == 0) {
