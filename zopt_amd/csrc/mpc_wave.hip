@@ -113,12 +113,14 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
     double* rw = base + 32 + li;
     double* kf = base + 48 + li;                   // (control lanes)
 
-    // the lane's column of [A | B] (the adjoint products over the state lanes) and its row of B (zero outside the state lanes)
-    double ABcol[NS], Brow[MC];
+    // the lane's column of [A | B] (the adjoint products over the state lanes), its row of A (state lanes; the control lanes' row of
+    // [A ; K_k] comes from the stage's table) and its row of B (zero outside the state lanes)
+    double ABcol[NS], Arow[NS], Brow[MC];
 #pragma unroll
     for (int l = 0; l < NS; ++l) {
-        const double ac = A[l * NS + ix], bc = B[l * MC + iu];
+        const double ac = A[l * NS + ix], bc = B[l * MC + iu], ar = A[ix * NS + l];
         ABcol[l] = sx ? ac : (su ? bc : 0.0);
+        Arow[l] = sx ? ar : 0.0;
     }
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
 
     // Table slices of one stage, by lane role, and the lane's own iterates of that stage from LDS (y, lam, kf: stage-local, so reading
     // them stages ahead of their use is safe in both sweeps: no LDS round trip at the head of a stage's dependency chain):
-    //     fwd[l]  the lane's row of [A ; K_k]          (state lanes: row of A, re-read from L2 like the others; control lanes: row of K_k)
+    //     fwd[l]  the lane's row of [A ; K_k]          (state lanes: row of A, kept; control lanes: row of K_k, loaded under their mask)
     //     adj[j]  the lane's row of [K_k^T ; Suu_k^-1]  (state lanes: column of K_k; control lanes: row of Suu_k^-1)
     // No masking: a lane outside every role (shapes with NS + MC < 16) loads the finite entries of row / column 0 and computes finite
     // values nobody reads -- only lanes < NS of p / x and lanes NS .. W-1 of qu / u are ever broadcast, only lanes < W are stored or
@@ -170,13 +172,18 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
         t.kf = kf[k * WS_STAGE];
         const double* Kk = Ktab + ((long)lvl * N + k) * MC * NS;
         const double* Mk = Mtab + ((long)lvl * N + k) * MC * MC;
-        const double* pf = su ? Kk + iu * NS : A + ix * NS;
         const double* pa = su ? Mk + iu * MC : Kk + ix;
         const int sa = su ? 1 : NS;
+        if (su) {   // (only the control lanes' rows change with the stage: the state lanes keep their row of A, set once per sweep)
 #pragma unroll
-        for (int i = 0; i < NS; ++i) t.fwd[i] = pf[i];
+            for (int i = 0; i < NS; ++i) t.fwd[i] = Kk[iu * NS + i];
+        }
 #pragma unroll
         for (int j = 0; j < MC; ++j) t.adj[j] = pa[j * sa];
+    };
+    auto init_tab = [&](Tab& t) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) t.fwd[i] = Arow[i];
     };
 
     const double alpha = g.alpha, om_alpha = 1.0 - g.alpha;
@@ -253,6 +260,9 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
                 x = sx ? xn : 0.0;
             };
             Tab t0, t1, t2;
+            init_tab(t0);
+            init_tab(t1);
+            init_tab(t2);
             load_tab(0, t0);
             load_tab(1, t1);
             load_tab(2, t2);
@@ -339,6 +349,7 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
         double x = x0;
         if (sx) g.xTraj[(inst * (N + 1)) * NS + ix] = x;
         Tab tf;
+        init_tab(tf);
 #pragma unroll 1
         for (int k = 0; k < N; ++k) {
             load_tab(k, tf);
