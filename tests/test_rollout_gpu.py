@@ -276,3 +276,38 @@ def test_reroll_as_its_own_launch_matches_the_second_pass(mods, N):
     assert np.all(x2[17] == -7.0) and np.all(i2[listed] >= 0) and len(set(i2[listed].tolist())) > 1   # several winners, not only alpha_0
     untouched = sorted(set(range(batch)) - set(lst.cpu().numpy().tolist()))
     assert np.all(x2[untouched] == -7.0) and np.all(J2[untouched] == -7.0)
+
+
+def test_fast_rollout_kernels_random_horizons_and_batches(mods):
+    """Seeded sweep over horizons (every remainder of the four-step loop body of rollout_ls_fast_kernel and of the three-step body of the
+    four-lane kernels) and batch sizes (groups that do not fill a wave, more waves than one) for the (12, 4) line search: forwardPass2 and
+    a single-step-size trajectoryRollout of the quadcopter and of a linear model, general and diagonal weights, against the oracle."""
+    ilqr, models, pt = mods
+    rng = np.random.default_rng(2025)
+    for case in range(10):
+        N = int(rng.integers(1, 23))
+        batch = int(rng.choice([1, 2, 3, 5, 17, 66]))
+        kind = "quadcopter" if case % 2 == 0 else "linear"
+        if kind == "linear":
+            model = models.LinearModel(rng.standard_normal((12, 12)) * (1.0 / np.sqrt(12)), rng.standard_normal((12, 4)))
+            x0, l, L, xPrev, uPrev = _random_policy_problem(rng, batch, N, 12, 4)
+            l *= 4.0
+            f = model
+        else:
+            model = models.QuadcopterEuler(0.1)
+            x0, l, L, xPrev, uPrev = _quad_problem(rng, batch, N)
+            l *= 40.0
+            f = zo.quad_euler_step(0.1)
+        if case % 3 == 0:
+            cost = models.QuadraticCost(np.diag(rng.uniform(0.5, 2.0, 12)), np.diag(rng.uniform(0.5, 2.0, 4)), np.diag(rng.uniform(5.0, 20.0, 12)))
+        else:
+            Mq, Mr = rng.standard_normal((12, 12)), rng.standard_normal((4, 4))
+            cost = models.QuadraticCost(Mq @ Mq.T / 12 + np.eye(12), Mr @ Mr.T / 4 + np.eye(4), 10 * np.eye(12))
+        traj, J = ilqr.forwardPass2(x0, model, cost, pt.AffinePolicy(l, L), pt.Trajectory(xPrev, uPrev))
+        one = ilqr.trajectoryRollout(x0, model, pt.AffinePolicy(l, L), pt.Trajectory(xPrev, uPrev), alpha=0.25)
+        for b in sorted(set([0, batch // 2, batch - 1])):
+            rt, rJ = zo.forwardPass2(x0[b], f, cost.runningCost, cost.terminalCost, zo.AffinePolicy(l[b], L[b]), zo.Trajectory(xPrev[b], uPrev[b]))
+            assert abs(J[b] - rJ) <= 1e-10 * abs(rJ), (case, kind, N, batch, b)
+            assert _rel(traj.xTraj[b], rt.xTraj) <= 1e-9 and _rel(traj.uTraj[b], rt.uTraj) <= 1e-9, (case, kind, N, batch, b)
+            r1 = zo.trajectoryRollout(x0[b], f, zo.AffinePolicy(l[b], L[b]), zo.Trajectory(xPrev[b], uPrev[b]), 0.25)
+            assert _rel(one.xTraj[b], r1.xTraj) <= 1e-9 and _rel(one.uTraj[b], r1.uTraj) <= 1e-9, (case, kind, N, batch, b)
