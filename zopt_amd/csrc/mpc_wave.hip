@@ -165,21 +165,31 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
         double fwd[NS], adj[MC];
         double y, lam, kf;
     };
+    // Table addresses: a per-lane base (role and penalty level: set at the top of every ADMM iteration) plus stage index x a per-lane
+    // stage stride -- one v_mad per table and stage; the elements of a slice sit at compile-time offsets on either side of the role mask.
+    // (Computed from lvl and k inside the stage, the addresses were a third of a backward stage's vector instructions.)
+    const char *adj_base = nullptr, *fwd_base = nullptr;
+    const unsigned adj_stride = (su ? MC * MC : MC * NS) * (unsigned)sizeof(double);
+    auto set_level_bases = [&]() {
+        adj_base = su ? (const char*)(Mtab + ((long)lvl * N * MC + iu) * MC) : (const char*)(Ktab + (long)lvl * N * MC * NS + ix);
+        fwd_base = (const char*)(Ktab + (long)lvl * N * MC * NS + iu * NS);
+    };
     auto load_tab = [&](int k, Tab& t) {
         k = k < 0 ? 0 : (k >= N ? N - 1 : k);
         t.y = yw[k * WS_STAGE];
         t.lam = lw[k * WS_STAGE];
         t.kf = kf[k * WS_STAGE];
-        const double* Kk = Ktab + ((long)lvl * N + k) * MC * NS;
-        const double* Mk = Mtab + ((long)lvl * N + k) * MC * MC;
-        const double* pa = su ? Mk + iu * MC : Kk + ix;
-        const int sa = su ? 1 : NS;
+        const double* pa = (const double*)(adj_base + (unsigned long long)(unsigned)k * adj_stride);
         if (su) {   // (only the control lanes' rows change with the stage: the state lanes keep their row of A, set once per sweep)
+            const double* pf = (const double*)(fwd_base + (unsigned long long)(unsigned)k * (unsigned)(MC * NS * sizeof(double)));
 #pragma unroll
-            for (int i = 0; i < NS; ++i) t.fwd[i] = Kk[iu * NS + i];
+            for (int i = 0; i < NS; ++i) t.fwd[i] = pf[i];
+#pragma unroll
+            for (int j = 0; j < MC; ++j) t.adj[j] = pa[j];           // row of Suu_k^-1
+        } else {
+#pragma unroll
+            for (int j = 0; j < MC; ++j) t.adj[j] = pa[j * NS];      // column of K_k
         }
-#pragma unroll
-        for (int j = 0; j < MC; ++j) t.adj[j] = pa[j * sa];
     };
     auto init_tab = [&](Tab& t) {
 #pragma unroll
@@ -195,6 +205,7 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
     for (int gi = 0; gi < g.max_iter; ++gi) {
         if (__all(done)) break;
         const bool chk = ((gi + 1) % ZM_MPC_CHK) == 0;
+        set_level_bases();
         // ---- backward affine sweep.  The table slices come from L2 (~500+ cycles) and a stage is shorter than that, so they are
         //      fetched THREE stages ahead into a rotating set of registers (the loop is unrolled by three: no copies).
         double pp = 0.0;   // (A^T p - K^T Qu) of the stage above (state lanes)
@@ -346,6 +357,7 @@ __global__ __launch_bounds__(64) void mpc_solve_wave_kernel(const double* __rest
     }
     // ---- final trajectory (the dynamics-exact rollout of the last iterate) and the iterates for a later warm start
     if (live) {
+        set_level_bases();
         double x = x0;
         if (sx) g.xTraj[(inst * (N + 1)) * NS + ix] = x;
         Tab tf;
