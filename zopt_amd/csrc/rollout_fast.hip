@@ -3,8 +3,9 @@
 // Same arithmetic as rollout.hip (reference ilqrUtils.py:33-66, 116-150; pytrees.py:49-52, 215-220); what changes:
 //  * compile-time model / dimensions: no predicated loops, no branches on the model kind;
 //  * a step's policy data [l_k | L_k | xPrev_k | uPrev_k] (68 doubles) is fetched ONCE per trajectory by the 16 lanes of
-//    its group with coalesced loads, one step ahead, into an LDS double buffer; the lanes then read it by broadcast
-//    (the generic kernel issued 68 redundant global loads per lane and step);
+//    its group with coalesced loads, three steps ahead, and stays in the loading lanes' registers: every use is an FMA whose DPP
+//    operand reads the owning lane (PolRegs below; the generic kernel issued 68 redundant global loads per lane and step, rounds
+//    1-2 staged the data in LDS);
 //  * cost matrices (and A, B of a linear model) live in LDS; diagonal Q, R, Qf (the demos' weights) use 12 + 4 FMAs;
 //  * the alpha = 1 lane stores its rollout speculatively during pass 1: pass 2 (re-roll of the winner) only runs for
 //    trajectories whose argmin is another step size;

@@ -4,8 +4,8 @@
 // is who computes it.  A rollout is a chain of T dependent steps of ~310 VALU instructions per lane, and a lone wave issues dependent fp64
 // instructions only every ~9.5 cycles (independent ones every 4.7): when few waves are in flight, the launch lasts as long as that chain.  Here the lanes of a quad
 // share one rollout: lane q computes row q of the policy product L_k (x - xPrev_k) and the sine / cosine of one Euler angle, and
-// loads only what it needs (row q of L_k, xPrev_k, l_k[q], uPrev_k[q]: 26 doubles instead of 68) straight from global memory, one
-// step ahead, in registers; controls and trigonometric values are exchanged by DPP quad broadcasts.  Dynamics, cost and state update
+// loads only what it needs (row q of L_k, xPrev_k, l_k[q], uPrev_k[q]: 26 doubles instead of 68) straight from global memory, two
+// steps ahead, in registers; controls and trigonometric values are exchanged by DPP quad broadcasts.  Dynamics, cost and state update
 // stay replicated (their formulas differ per component: four lanes would diverge, not share).  ~200 instructions per step.
 //
 //  rollout_quad_all_kernel     the solvers' all-store line search (few trajectories left): one trajectory per wave, 16 step sizes x
