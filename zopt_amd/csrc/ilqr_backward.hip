@@ -119,6 +119,25 @@ __device__ __forceinline__ void ilqr_load_step(IlqrStepRegs<KS>& d, IlqrAddr<KS>
 //                       MODE 1: [96,112) V^T d (column-indexed); [112,116) l
 constexpr int ILQR_LDS_DOUBLES = 116;
 
+// Diagnostic build (-DZM_SWEEP_LAB): s_memtime stamps at the phase boundaries of a step of the ring kernel, summed by wave 0 of block 0
+// into zm_sweep_stamps (read back with zm_lab_sweep_stamps).  The stamps' waits forbid overlaps the product has: read SHARES.
+#ifdef ZM_SWEEP_LAB
+__device__ unsigned long long zm_sweep_stamps[10];
+struct SweepLab {
+    unsigned long long acc[8], last;
+};
+#define ZM_SWEEP_STAMP(lab, q)                                                                         \
+    do {                                                                                              \
+        unsigned long long t_;                                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+        (lab)->acc[q] += t_ - (lab)->last;                                                            \
+        (lab)->last = t_;                                                                             \
+    } while (0)
+#else
+struct SweepLab {};
+#define ZM_SWEEP_STAMP(lab, q) do { } while (0)
+#endif
+
 __device__ __forceinline__ void ilqr_lds_sync() { wave_lds_sync(); }
 
 // ZIN (MODE 2, the DMA kernel): the caller has contracted vf_zz = sum_i v_x[i] d2f_i/dz2 already (operands in its LDS ring) and
@@ -127,7 +146,8 @@ template <int KS, int MODE, bool PREFETCH, int ZIN = 0>
 __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], IlqrStepRegs<KS>& d, IlqrAddr<KS>& a,
                                           double* sm, const int g, const int c, const int ob0, const int ob1,
                                           const int ob2, const int ob3, const int oqa, double* jA, double* jV,
-                                          double* jcs, int* jpq, const int n, const int m, const d4 zin = d4{0.0, 0.0, 0.0, 0.0}) {
+                                          double* jcs, int* jpq, const int n, const int m, const d4 zin = d4{0.0, 0.0, 0.0, 0.0},
+                                          SweepLab* lab = nullptr) {
     constexpr int NP = 4 * KS;
     // MODE 2: vf_zz = sum_i v_x[i] * d2f_i/dz2, PD-projected, as extra accumulator init
     d4 pz = zero4();
@@ -240,6 +260,7 @@ __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], 
     const double qv = d.cv + qp;
     if constexpr (PREFETCH) ilqr_load_step<KS, MODE>(d, a);
 
+    ZM_SWEEP_STAMP(lab, 2);   // projection (MODE 2), the six MFMAs of G, the vector terms
     // solve: tile + q row through LDS
     sm[g * 16 + c] = gacc[KS];
     if (g == 0) sm[64 + c] = qv;
@@ -259,7 +280,13 @@ __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], 
     const double quu_a = sm[oqa];  // Q_uu[c][g]: A operand of Q_uu L (0-padded through the address choice below)
     __builtin_amdgcn_wave_barrier();
     const double b0[4] = {b[0], b[1], b[2], b[3]};  // original right-hand side (Sux column) for MODE 1's v' update
+    ZM_SWEEP_STAMP(lab, 3);   // the exchange through LDS
     if (__builtin_amdgcn_ballot_w64(!lu_solve4_nopivot(S, b, x)) != 0ull) lu_solve4_fallback(S, b, x);
+    {
+        double keep = x[0] + x[1] + x[2] + x[3];
+        asm volatile("" : "+v"(keep));
+    }
+    ZM_SWEEP_STAMP(lab, 4);   // the 4 x 4 solve
     const double x01 = (g & 1) ? x[1] : x[0];
     const double x23 = (g & 1) ? x[3] : x[2];
     const double xg = (g & 2) ? x23 : x01;
@@ -306,6 +333,7 @@ __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], 
 #pragma unroll
     for (int s = 0; s < KS; ++s) vxr[s] = sm[80 + 4 * s + g];
     __builtin_amdgcn_wave_barrier();
+    ZM_SWEEP_STAMP(lab, 5);   // store, value terms, the two MFMAs of V', v_x through LDS
 }
 
 template <int KS, int MODE>
@@ -747,11 +775,20 @@ __global__ __launch_bounds__(64 * W, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_
     for (int i = 0; i < D; ++i)
         if (T - 1 - i >= 0) dma(lds + i * SLOT);
     int j = T - 1;
+#ifdef ZM_SWEEP_LAB
+    SweepLab labv;
+    for (int q = 0; q < 8; ++q) labv.acc[q] = 0ull;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(labv.last)::"memory");
+    SweepLab* const lab = &labv;
+#else
+    SweepLab* const lab = nullptr;
+#endif
     for (;;) {
 #pragma unroll
         for (int si = 0; si < D; ++si) {
             char* slot = lds + si * SLOT;
             wait_for_step<NI, D>(j);
+            ZM_SWEEP_STAMP(lab, 0);   // waiting for the step's DMA
             IlqrStepRegs<KS> d;
             if constexpr (!DIET) {
 #pragma unroll
@@ -830,13 +867,22 @@ __global__ __launch_bounds__(64 * W, MODE == 2 ? ZM_DDP_DMA_WAVES : ZM_ILQR_DMA_
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // operands are in registers: the slot may be refilled
             if (j - D >= 0) dma(slot);
+            ZM_SWEEP_STAMP(lab, 1);   // operand reads (and MODE 2's contraction), DMA issue
             if constexpr (DIET)
                 ilqr_step<KS, MODE, false, 2>(Vxx, vxr, d, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, jA, nullptr, nullptr, nullptr, N, M, zin);
             else if constexpr (MODE == 2)
-                ilqr_step<KS, MODE, false, 1>(Vxx, vxr, d, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, jA, nullptr, nullptr, nullptr, N, M, zin);
+                ilqr_step<KS, MODE, false, 1>(Vxx, vxr, d, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, jA, nullptr, nullptr, nullptr, N, M, zin, lab);
             else
-                ilqr_step<KS, MODE, false>(Vxx, vxr, d, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, nullptr, nullptr, nullptr, nullptr, N, M);
-            if (--j < 0) return;
+                ilqr_step<KS, MODE, false>(Vxx, vxr, d, a, sm, g, c, ob0, ob1, ob2, ob3, oqa, nullptr, nullptr, nullptr, nullptr, N, M, zero4(), lab);
+            if (--j < 0) {
+#ifdef ZM_SWEEP_LAB
+                if (blockIdx.x == 0 && threadIdx.x == 0) {
+                    for (int q = 0; q < 8; ++q) atomicAdd(&zm_sweep_stamps[q], labv.acc[q]);
+                    atomicAdd(&zm_sweep_stamps[8], 1ull);
+                }
+#endif
+                return;
+            }
         }
     }
 }
@@ -1144,3 +1190,15 @@ extern "C" int zm_riccati_value_f64(const double* f_x, const double* f_u, const 
     return zm::launch_ilqr<0>(f_x, f_u, c_x, c_u, c_xx, c_ux, c_uu, vf_x, vf_xx, nullptr, (long)n, (long)n * n, nullptr, 0, l, L,
                               batch, T, n, m, (hipStream_t)stream, zm::DdpTensors{nullptr, nullptr, nullptr}, v);
 }
+
+#ifdef ZM_SWEEP_LAB
+extern "C" int zm_lab_sweep_stamps(unsigned long long* out, int reset) {
+    ZM_HIP_CHECK(hipDeviceSynchronize());
+    ZM_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(zm::zm_sweep_stamps), sizeof(unsigned long long) * 10));
+    if (reset) {
+        unsigned long long z[10] = {0};
+        ZM_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(zm::zm_sweep_stamps), z, sizeof(z)));
+    }
+    return ZM_OK;
+}
+#endif
