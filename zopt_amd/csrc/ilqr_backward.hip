@@ -244,10 +244,7 @@ __device__ __forceinline__ void ilqr_step(double (&Vxx)[KS], double (&vxr)[KS], 
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             double vd = Vxx[s] * d.dc;  // (V d)[4s+g]: row reduction over the 16 lanes of the group
-            vd += __shfl_xor(vd, 1);
-            vd += __shfl_xor(vd, 2);
-            vd += __shfl_xor(vd, 4);
-            vd += __shfl_xor(vd, 8);
+            vd = row16_sum(vd);   // (DPP butterflies: the bits of the __shfl_xor ladder over 1, 2, 4, 8 without its eight ds_bpermute)
             const double w = vxr[s] + (a.cA ? vd : sm[96 + 4 * s + g]);
             qp = __builtin_fma(d.F[s], w, qp);
         }

@@ -75,16 +75,9 @@ __device__ __forceinline__ void mv_seq(const double (&c)[NL], const double v, do
 __device__ __forceinline__ void amax(double& acc, const double v) {
     asm("v_max_f64 %0, %0, |%1|" : "+v"(acc) : "v"(v));
 }
-__device__ __forceinline__ double row_max(double v) {
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) v = __builtin_fmax(v, __shfl_xor(v, off, 16));
-    return v;
-}
-__device__ __forceinline__ double row_sum(double v) {
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, 16);
-    return v;
-}
+// (DPP butterflies: the __shfl_xor ladders they replace were eight ds_bpermute round trips per reduction, five reductions per iteration)
+__device__ __forceinline__ double row_max(double v) { return row16_max(v); }
+__device__ __forceinline__ double row_sum(double v) { return row16_sum_from8(v); }
 
 // LDS per group and stage (doubles): y[16] lam[16] r[16] kf[16], one slot per lane
 constexpr int WS_STAGE = 64;

@@ -29,15 +29,10 @@ constexpr int NS_LDS_DOUBLES = 2 * 16 * NS_LD;
 
 __device__ __forceinline__ void ns_sync() { wave_lds_sync(); }
 
-// 32-bit halves of a double through one DPP move (VALU speed; __shfl_xor would be two ds_bpermute round trips per level)
+// (dpp_mov64 of zm_common.h under its older name)
 template <int CTRL>
 __device__ __forceinline__ double ns_dpp(const double v) {
-    const long long b = __builtin_bit_cast(long long, v);
-    // mov_dpp with bound_ctrl: every lane of these in-row permutations has a valid source, so the destination needs no initial value
-    // (update_dpp(0, ...) made the compiler zero-fill it first: four instructions per double instead of two)
-    const int lo = __builtin_amdgcn_mov_dpp((int)b, CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xf, 0xf, true);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+    return dpp_mov64<CTRL>(v);
 }
 
 __device__ __forceinline__ double ns_readlane(const double v, const int l) {

@@ -53,6 +53,43 @@ __device__ __forceinline__ void wave_lds_sync() {
 #endif
 }
 
+// 32-bit halves of a double through one DPP move each (VALU speed; __shfl_xor is two ds_bpermute round trips through the LDS crossbar
+// per level).  mov_dpp with bound_ctrl: every lane of these in-row permutations has a valid source, so the destination needs no
+// initial value.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov64(const double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)b, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// Sum / maximum over the 16 lanes of a row, the result in every lane of the row: butterflies by quad_perm (xor 1, xor 2),
+// row_half_mirror and row_mirror.  The same bits as the __shfl_xor butterfly over offsets 1, 2, 4, 8: after the quad steps every lane of
+// a quad holds the quad's value, so the mirrored partner of a step holds exactly what the xor partner holds, and + / max commute.
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_mov64<0xB1>(v);
+    v += dpp_mov64<0x4E>(v);
+    v += dpp_mov64<0x141>(v);
+    v += dpp_mov64<0x140>(v);
+    return v;
+}
+// The same sum in the order of a ladder that starts at offset 8: row_ror:8 is lane ^ 8 on 16 lanes; after it the values repeat with
+// period 8, so row_ror:4 delivers what lane ^ 4 holds; then the quad steps.  Bits of `for (off = 8; off >= 1; off >>= 1) v += shfl_xor`.
+__device__ __forceinline__ double row16_sum_from8(double v) {
+    v += dpp_mov64<0x128>(v);
+    v += dpp_mov64<0x124>(v);
+    v += dpp_mov64<0x4E>(v);
+    v += dpp_mov64<0xB1>(v);
+    return v;
+}
+__device__ __forceinline__ double row16_max(double v) {
+    v = __builtin_fmax(v, dpp_mov64<0xB1>(v));
+    v = __builtin_fmax(v, dpp_mov64<0x4E>(v));
+    v = __builtin_fmax(v, dpp_mov64<0x141>(v));
+    v = __builtin_fmax(v, dpp_mov64<0x140>(v));
+    return v;
+}
+
 // v + (the value of lane ^ 16) resp. lane ^ 32, by the gfx950 row / half-wave swaps (VALU; __shfl_xor across rows is a ds_bpermute
 // round trip through LDS on the dependency chain).  permlane16_swap(a, b): odd rows of a <-> even rows of b; with a = b = v the two
 // results hold the even-row resp. odd-row partner values of every row pair, whose sum is the butterfly sum in both rows (fp addition
