@@ -36,9 +36,7 @@ __device__ __forceinline__ void tm_op(const TMat<NT>& X, const TMat<NT>& Y, TMat
 
 template <int NT>
 __device__ __forceinline__ double tm_wave_sum(double v) {
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 16);
-    return sum_xor32(sum_xor16(v));
+    return sum_xor32(sum_xor16(row16_sum(v)));
 }
 
 // M <- (M + M^T) / 2, tile pair by tile pair through two LDS buffers

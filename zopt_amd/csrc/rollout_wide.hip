@@ -99,9 +99,7 @@ __device__ __forceinline__ double wide_rollout(const WideArgs& g, const WideRows
         }
         Jl = __builtin_fma(xi, qf, Jl);
     }
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) Jl += __shfl_xor(Jl, off, 16);
-    return sum_xor32(sum_xor16(Jl));
+    return sum_xor32(sum_xor16(row16_sum(Jl)));
 }
 
 template <int NP>

@@ -193,8 +193,7 @@ __global__ __launch_bounds__(64) void sweep_tiled_f64(const SweepTiledArgs a) {
                     double p = 0.0;
 #pragma unroll
                     for (int J = 0; J < NT; ++J) p = __builtin_fma(V[K][J][r], dc[J], p);
-#pragma unroll
-                    for (int off = 1; off < 16; off <<= 1) p += __shfl_xor(p, off, 16);
+                    p = row16_sum(p);   // (DPP butterflies, the bits of the __shfl_xor ladder over 1, 2, 4, 8)
                     tr_[K][r] += p;                                    // v + V d      (lqrUtils.py:251)
                 }
             t_lds_sync();
