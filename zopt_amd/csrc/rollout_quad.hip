@@ -57,10 +57,9 @@ __device__ __forceinline__ void quad_load(QuadOps& o, const double* Lr, const do
     o.upq = upq[k * QM];
 }
 
-// one step: u = (alpha l_k + L_k (x - xPrev_k)) + uPrev_k  (pytrees.py:220, ilqrUtils.py:59-60), cost, x <- f(x, u)
-template <bool COST>
-__device__ __forceinline__ void quad_step(const QuadOps& o, const int q, const double al, const double dt, const double (&qd)[QN],
-                                          const double (&rd)[QM], double (&x)[QN], double (&u)[QM], double& J) {
+// one step in two halves.  First half: u = (alpha l_k + L_k (x - xPrev_k)) + uPrev_k  (pytrees.py:220, ilqrUtils.py:59-60) -- the only
+// part that reads the step's operand registers, which the caller then refills for the step after next while the second half runs.
+__device__ __forceinline__ void quad_policy(const QuadOps& o, const double al, const double (&x)[QN], double (&u)[QM]) {
     double dx[QN];
 #pragma unroll
     for (int j = 0; j < QN; ++j) dx[j] = x[j] - o.xp[j];
@@ -72,16 +71,24 @@ __device__ __forceinline__ void quad_step(const QuadOps& o, const int q, const d
     u[1] = quad_bcast<1>(uq);
     u[2] = quad_bcast<2>(uq);
     u[3] = quad_bcast<3>(uq);
-    if constexpr (COST) {   // rollout_fast.hip's diagonal quad_form, in its order
-        double jx = 0.0, ju = 0.0;
+}
+// second half: cost (rollout_fast.hip's diagonal quad_form, in its order) ...
+__device__ __forceinline__ void quad_cost(const double (&qd)[QN], const double (&rd)[QM], const double (&x)[QN], const double (&u)[QM],
+                                          double& J) {
+    double jx = 0.0, ju = 0.0;
 #pragma unroll
-        for (int j = 0; j < QN; ++j) jx = __builtin_fma(x[j] * qd[j], x[j], jx);
+    for (int j = 0; j < QN; ++j) jx = __builtin_fma(x[j] * qd[j], x[j], jx);
 #pragma unroll
-        for (int j = 0; j < QM; ++j) ju = __builtin_fma(u[j] * rd[j], u[j], ju);
-        J += jx + ju;
-    }
+    for (int j = 0; j < QM; ++j) ju = __builtin_fma(u[j] * rd[j], u[j], ju);
+    J += jx + ju;
+}
+// ... and x <- f(x, u)
+__device__ __forceinline__ void quad_advance(const int q, const double dt, double (&x)[QN], const double (&u)[QM]) {
     // lane q < 3: sine and cosine of Euler angle q (lane 3 repeats psi); everyone receives all three pairs
-    const double ang = (q == 0) ? x[6] : ((q == 1) ? x[7] : x[8]);
+    // (two selects kept apart: written as one expression the compiler indexes x[6 + min(q, 2)] dynamically and moves x to scratch)
+    double ang = (q == 1) ? x[7] : x[8];
+    asm("" : "+v"(ang));
+    ang = (q == 0) ? x[6] : ang;
     double sq, cq;
     zm_sincos(ang, &sq, &cq);
     const double sphi = quad_bcast<0>(sq), cphi = quad_bcast<0>(cq);
@@ -125,14 +132,18 @@ __global__ __launch_bounds__(256) void rollout_quad_all_kernel(const QuadArgs g)
         for (int i = 0; i < QN; ++i) so[(i >> 1) * 32 + (i & 1)] = x[i];
     }
     double J = 0.0;
-    // operands TWO steps ahead in three rotating register sets: with ~1000 trajectories in flight the operands come from HBM, and one
-    // step of this chain (~0.8 us) is shorter than that round trip under load
-    QuadOps oa, ob, oc;
+    // Two operand sets, each refilled for the step after next as soon as its step's policy half has read it -- i.e. while the rest of
+    // that step (cost, sincos, dynamics: three quarters of it) and the whole next step run: ~1.75 steps of prefetch distance (with ~1000
+    // trajectories in flight the operands come from HBM, and one step of this chain, ~0.8 us, is shorter than that round trip under
+    // load) at the register cost of one step ahead (three rotating sets spilt 58 registers to AGPRs: 34 moves per step).
+    QuadOps oa, ob;
     quad_load(oa, Lr, xp, lq, upq, 0);
     if (T > 1) quad_load(ob, Lr, xp, lq, upq, 1);
-    auto body = [&](const QuadOps& cur, QuadOps& nxt2, const int k) {
-        if (k + 2 < T) quad_load(nxt2, Lr, xp, lq, upq, k + 2);
-        quad_step<true>(cur, q, al, g.dt, qd, rd, x, u, J);
+    auto body = [&](QuadOps& cur, const int k) {
+        quad_policy(cur, al, x, u);
+        if (k + 2 < T) quad_load(cur, Lr, xp, lq, upq, k + 2);
+        quad_cost(qd, rd, x, u, J);
+        quad_advance(q, g.dt, x, u);
         if (st) {
             double* sb = so + (long)(k + 1) * Q_ALLSTORE_BLOCK;
 #pragma unroll
@@ -142,13 +153,11 @@ __global__ __launch_bounds__(256) void rollout_quad_all_kernel(const QuadArgs g)
         }
     };
     int k = 0;
-    for (; k + 2 < T; k += 3) {   // rotating operand registers: no copies
-        body(oa, oc, k);
-        body(ob, oa, k + 1);
-        body(oc, ob, k + 2);
+    for (; k + 1 < T; k += 2) {   // ping-pong operand registers: no copies
+        body(oa, k);
+        body(ob, k + 1);
     }
-    if (k < T) body(oa, oc, k);
-    if (k + 1 < T) body(ob, oa, k + 1);
+    if (k < T) body(oa, k);
     {   // terminal cost, rollout_fast.hip's diagonal quad_form
         double jf = 0.0;
 #pragma unroll
@@ -192,7 +201,6 @@ __global__ __launch_bounds__(64) void rollout_quad_reroll_kernel(const QuadArgs 
     const double* xp = g.xPrev + t * (T + 1) * QN;
     const double* lq = g.l + t * T * QM + q;
     const double* upq = g.uPrev + t * T * QM + q;
-    const double qd[QN] = {0.0}, rd[QM] = {0.0};
     double x[QN], u[QM];
 #pragma unroll
     for (int i = 0; i < QN; ++i) x[i] = g.x0[t * QN + i];
@@ -203,13 +211,13 @@ __global__ __launch_bounds__(64) void rollout_quad_reroll_kernel(const QuadArgs 
 #pragma unroll
         for (int i = 0; i < QN; ++i) xo[i] = x[i];
     }
-    double J = 0.0;
-    QuadOps oa, ob, oc;   // operands two steps ahead, as in rollout_quad_all_kernel
+    QuadOps oa, ob;   // refilled right after the policy half of their step, as in rollout_quad_all_kernel
     quad_load(oa, Lr, xp, lq, upq, 0);
     if (T > 1) quad_load(ob, Lr, xp, lq, upq, 1);
-    auto body = [&](const QuadOps& cur, QuadOps& nxt2, const int k) {
-        if (k + 2 < T) quad_load(nxt2, Lr, xp, lq, upq, k + 2);
-        quad_step<false>(cur, q, al, g.dt, qd, rd, x, u, J);
+    auto body = [&](QuadOps& cur, const int k) {
+        quad_policy(cur, al, x, u);
+        if (k + 2 < T) quad_load(cur, Lr, xp, lq, upq, k + 2);
+        quad_advance(q, g.dt, x, u);
         if (st) {
 #pragma unroll
             for (int i = 0; i < QM; ++i) uo[(long)k * QM + i] = u[i];
@@ -218,13 +226,11 @@ __global__ __launch_bounds__(64) void rollout_quad_reroll_kernel(const QuadArgs 
         }
     };
     int k = 0;
-    for (; k + 2 < T; k += 3) {
-        body(oa, oc, k);
-        body(ob, oa, k + 1);
-        body(oc, ob, k + 2);
+    for (; k + 1 < T; k += 2) {
+        body(oa, k);
+        body(ob, k + 1);
     }
-    if (k < T) body(oa, oc, k);
-    if (k + 1 < T) body(ob, oa, k + 1);
+    if (k < T) body(oa, k);
 }
 
 // rollout_fast.hip decides when these apply (quadcopter in still air, diagonal weights asserted, 16 step sizes)
