@@ -65,7 +65,7 @@ def mpc_utilisation(batch):
                     "lds_bank_conflict_of_lds_active": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_ACTIVE_INST_LDS"],
                     "source": "profiles/r03_mpc_pmc.txt (rocprofv3 --pmc passes of mpc_solve_wave_kernel<12,4>, 1024 instances, eps 1e-2)",
                     "reading": "a latency chain: one wave per SIMD on a quarter of the SIMDs, 60 dependent stages per ADMM iteration; "
-                               "the wave issues VALU in 54 % of its cycles, the chip's VALU is therefore ~13 % busy"})
+                               "the wave issues VALU in 44 % of its cycles (34 % waiting on table loads and LDS), the chip's VALU is therefore ~11 % busy"})
     except Exception as e:  # noqa: BLE001
         out["source"] = f"profiles/r03_mpc_pmc.txt not readable ({type(e).__name__})"
     return out
